@@ -1,0 +1,156 @@
+"""ctypes declarations of include/glabc.h and the loader of the HIP library.
+
+The structures below are the Python spelling of the C ABI in ``include/glabc.h``
+(field for field, same order).  ``lib()`` loads ``libglabc_hip.so`` -- the
+hand-written gfx950 kernels plus their C entry points, built in-tree by
+``__graft_entry__.build()`` -- and raises if it is missing: there is no CPU or
+PyTorch fallback for the sampler hot path.
+"""
+import ctypes as C
+import os
+
+MAX_DIM = 8
+MAX_BATCH = 16
+
+DIST_DIAG_GAUSS = 0
+DIST_UNIFORM = 1
+DIST_GAMMA = 2
+
+SIM_ABS_GAUSS = 0
+
+FLAG_LOCAL = 1
+
+OK = 0
+
+_f8 = C.c_float * MAX_DIM
+
+
+class Dist(C.Structure):
+    """struct glabc_dist"""
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("dim", C.c_int32),
+        ("p0", _f8),
+        ("p1", _f8),
+        ("p2", _f8),
+        ("c0", C.c_float),
+    ]
+
+
+class Model(C.Structure):
+    """struct glabc_model"""
+    _fields_ = [
+        ("sim_kind", C.c_int32),
+        ("theta_dim", C.c_int32),
+        ("y_dim", C.c_int32),
+        ("reserved", C.c_int32),
+        ("prior", Dist),
+        ("noise", Dist),
+        ("y_obs", _f8),
+        ("kern_log_scale", C.c_float),
+        ("kern_scale", C.c_float),
+        ("kern_c0", C.c_float),
+        ("epsilon", C.c_float),
+    ]
+
+
+class Chains(C.Structure):
+    """struct glabc_chains (device pointers as integers)"""
+    _fields_ = [
+        ("n_chains", C.c_int64),
+        ("chain0", C.c_int64),
+        ("stride", C.c_int64),
+        ("theta", C.c_void_p),
+        ("y", C.c_void_p),
+        ("log_w", C.c_void_p),
+        ("flags", C.c_void_p),
+        ("n_moves", C.c_void_p),
+    ]
+
+
+class Moments(C.Structure):
+    """struct glabc_moments"""
+    _fields_ = [
+        ("sum_theta", C.c_void_p),
+        ("sum_outer", C.c_void_p),
+        ("sum_jump", C.c_void_p),
+    ]
+
+
+class Tape(C.Structure):
+    """struct glabc_tape"""
+    _fields_ = [
+        ("u", C.c_void_p),
+        ("r", C.c_void_p),
+        ("z", C.c_void_p),
+        ("n_prop", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Run(C.Structure):
+    """struct glabc_run"""
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("step0", C.c_uint32),
+        ("n_steps", C.c_int32),
+        ("global_frequency", C.c_float),
+        ("batch_size", C.c_int32),
+        ("history", C.c_void_p),
+        ("hist_stride", C.c_int64),
+        ("moments", C.POINTER(Moments)),
+        ("tape", C.POINTER(Tape)),
+    ]
+
+
+_P = C.POINTER
+
+# name -> (restype, argtypes); the same table describes oracle_* twins minus the stream
+ENTRY_POINTS = {
+    "glabc_glmcmc_steps": (C.c_int, [_P(Model), _P(Dist), _P(Dist), _P(Chains), _P(Run), C.c_void_p]),
+    "glabc_globalmcmc_steps": (C.c_int, [_P(Model), _P(Dist), _P(Dist), _P(Chains), _P(Run), C.c_void_p]),
+    "glabc_init_weights": (C.c_int, [_P(Model), _P(Dist), _P(Chains), C.c_void_p]),
+    "glabc_dist_log_prob": (C.c_int, [_P(Dist), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_model_prior_log_prob": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_model_discrepancy": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_model_log_kernel": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_esjd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_moments_esjd": (C.c_int, [_P(Moments), C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_version": (C.c_int, []),
+    "glabc_status_string": (C.c_char_p, [C.c_int]),
+    "glabc_last_hip_error": (C.c_int, []),
+}
+
+LIB_NAME = "libglabc_hip.so"
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "csrc", LIB_NAME)
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded C-ABI library; raises HipLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                "%s not found: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). The sampler hot path has no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in ENTRY_POINTS.items():
+            fn = getattr(handle, name)     # AttributeError here = ABI mismatch, deliberately loud
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != OK:
+        msg = lib().glabc_status_string(status)
+        raise RuntimeError("%s failed: %s (status %d, hipError %d)" % (
+            what, msg.decode() if msg else "?", status, lib().glabc_last_hip_error()))

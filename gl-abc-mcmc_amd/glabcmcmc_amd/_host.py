@@ -1,0 +1,77 @@
+"""Host-side pieces the sampler functions share: argument normalisation, the
+reference's CSV side effect and its end-of-run summary print."""
+import csv
+
+import torch
+
+from . import engine
+
+
+def prepare(ABCset, Initial_theta, Initial_y, device, chain0):
+    dev = engine.require_device(device)
+    theta0 = torch.as_tensor(Initial_theta, dtype=torch.float32).detach().cpu()
+    single = theta0.dim() == 1 or theta0.shape[0] == 1
+    chains = engine.ChainBatch(theta0, torch.as_tensor(Initial_y).detach().cpu(), dev, chain0=chain0)
+    if chains.d != ABCset.theta_dim:
+        raise ValueError("Initial_theta has %d columns, Model.theta_dim is %d" % (chains.d, ABCset.theta_dim))
+    return dev, chains, single
+
+
+def allocate_history(num_ite, chains, record_history):
+    """Theta_Re in chain-major layout [num_ite][d][C]; row 0 = Initial_theta (GLMCMC.py:56-57)."""
+    if not record_history:
+        return None
+    hist = torch.empty(num_ite, chains.d, chains.n, dtype=torch.float32, device=chains.device)
+    hist[0].copy_(chains.theta)
+    return hist
+
+
+def finish(hist, chains, single, filelocation, csv_variant, verbose, return_device):
+    """What the reference does after its loop: CSV rows, summary print, return Theta_Re."""
+    if hist is None:
+        return None
+    if single:
+        Theta_Re = hist[:, :, 0].cpu()                             # (num_ite, d) float32 CPU, as the reference returns
+        if filelocation is not None:
+            write_csv(Theta_Re, filelocation, csv_variant)
+        if verbose:
+            print_summary(Theta_Re)
+        return Theta_Re.to(chains.device) if return_device else Theta_Re
+    out = hist.permute(0, 2, 1)                                    # (num_ite, C, d) view of the chain-major buffer
+    if filelocation is not None:
+        write_csv(out.reshape(out.shape[0], -1).cpu(), filelocation, csv_variant)
+    return out if return_device else out.cpu()
+
+
+def write_csv(Theta_Re, filelocation, variant):
+    """The reference's progress dump: header row = theta0, then blocks of rows appended
+    every 10 000 iterations and at the end.  variant 'glmcmc' is GLMCMC.py:105-111
+    (k = (i-1)//10000); variant 'global' is GlobalMCMC.py:70-76 == GLMALA.py:201-207 ==
+    GLMCMC_NFs.py:153-159 (k = i//10000, start (k-1)*10000+1), which re-writes the previous
+    block at the tail -- reproduced, since downstream scripts read the file as written."""
+    num_ite = Theta_Re.shape[0]
+    rows = Theta_Re.numpy()
+    with open(filelocation, "w", newline="", encoding="utf-8") as f:
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for i in range(1, num_ite):
+            if i % 10000 == 0 or i == num_ite - 1:
+                if variant == "glmcmc":
+                    start = max(1, ((i - 1) // 10000) * 10000 + 1)
+                else:
+                    start = max(1, (i // 10000 - 1) * 10000 + 1)
+                for j in range(start, i + 1):
+                    w.writerow(rows[j])
+
+
+def print_summary(Theta_Re):
+    """GLMCMC.py:113-136: per-coordinate mean, variance and 1.96-sigma interval."""
+    means = torch.mean(Theta_Re, dim=0)
+    variances = torch.var(Theta_Re, dim=0)
+    for i in range(Theta_Re.size(1)):
+        mean = means[i].item()
+        margin = 1.96 * torch.std(Theta_Re[:, i])
+        print(f"Theta_Re {i + 1}:")
+        print(f"  Mean: {mean:.4f}")
+        print(f"  Variance: {variances[i].item():.4f}")
+        print(f"  95% Confidence Interval: {(mean - margin, mean + margin)}")

@@ -1,0 +1,186 @@
+/*
+ * glabc.h -- C ABI of the MI355X-native GL-ABC-MCMC hot path.
+ *
+ * The reference (caofff/GL-ABC-MCMC, /root/reference) has no FFI of its own:
+ * its hot path is the body of three Python loops,
+ *     GlobalMCMC  glabcmcmc/GlobalMCMC.py:37-68
+ *     GLMCMC      glabcmcmc/GLMCMC.py:58-104
+ *     GLMALA      glabcmcmc/GLMALA.py:150-200
+ * calling distribution.{DiagGaussian,Uniform,Gamma} (glabcmcmc/distribution.py)
+ * and the user's Model callbacks (glabcmcmc/examples/Mixture.py:13-45).  Each
+ * entry point below replaces one of those loop bodies (or one distribution /
+ * ESJD.py call) for a whole batch of independent chains; the Python package
+ * glabcmcmc_amd binds them with ctypes (INTEGRATION.md shows the stub a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types.
+ *   - every pointer inside glabc_chains / glabc_run is a DEVICE pointer
+ *     (hipMalloc'd or a torch CUDA tensor's data_ptr); descriptor structs
+ *     themselves are read on the host at call time and may live on the stack.
+ *   - calls are stream-ordered on `stream` (a hipStream_t passed as void*;
+ *     NULL = the null stream), allocate nothing, keep no global state, and
+ *     are safe to call concurrently on different streams / chain sets.
+ *   - return 0 on success or a negative glabc_status; never throw.
+ *   - chain state is structure-of-arrays, chain index innermost
+ *     ("chain-major"): component j of chain c is at  base[j*stride + c], so a
+ *     64-lane wavefront reads 256 contiguous bytes per component.
+ *   - random numbers: Philox4x32-10 keyed by the 64-bit seed with counter
+ *     (global chain id, step, slot) -- include/glabc_numerics.h -- so results
+ *     do not depend on launch geometry, on n_steps per call, or on how chains
+ *     are sharded over GPUs (chain0 carries the shard offset).
+ */
+#ifndef GLABC_H
+#define GLABC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLABC_VERSION 100          /* 0.1.0 */
+#define GLABC_MAX_DIM 8            /* theta_dim, y_dim, distribution dim */
+#define GLABC_MAX_BATCH 16         /* iSIR proposals per step held in registers */
+
+typedef enum glabc_status {
+    GLABC_OK = 0,
+    GLABC_ERR_NULL = -1,           /* a required pointer is NULL */
+    GLABC_ERR_DIM = -2,            /* dimension out of range / not compiled in */
+    GLABC_ERR_KIND = -3,           /* distribution / simulator kind not supported by this entry point */
+    GLABC_ERR_ARG = -4,            /* bad scalar argument (n_steps < 0, batch_size out of range, ...) */
+    GLABC_ERR_LAUNCH = -5,         /* hipLaunchKernel failed; see glabc_last_hip_error() */
+    GLABC_ERR_NO_DEVICE = -6       /* no HIP device / wrong architecture */
+} glabc_status;
+
+/* ---- distributions: glabcmcmc/distribution.py ---------------------------- */
+typedef enum glabc_dist_kind {
+    GLABC_DIST_DIAG_GAUSS = 0,     /* distribution.py:143-181 */
+    GLABC_DIST_UNIFORM = 1,        /* distribution.py:50-86   */
+    GLABC_DIST_GAMMA = 2           /* distribution.py:90-137  */
+} glabc_dist_kind;
+
+typedef struct glabc_dist {
+    int32_t kind;                  /* glabc_dist_kind */
+    int32_t dim;
+    float p0[GLABC_MAX_DIM];       /* DiagGaussian loc        | Uniform low        | Gamma shape */
+    float p1[GLABC_MAX_DIM];       /* DiagGaussian log_scale  | Uniform high       | Gamma rate  */
+    float p2[GLABC_MAX_DIM];       /* DiagGaussian exp(log_scale) exactly as the caller's exp returned it
+                                      (distribution.py:170,178 recompute it per call; the round trip
+                                      exp(log(s)) != s matters for bit parity) | Uniform high-low | unused */
+    float c0;                      /* DiagGaussian f32(-0.5*dim*log(2*pi)) (distribution.py:171,177)
+                                      | Uniform log_prob_val (distribution.py:71) | unused */
+} glabc_dist;
+
+/* ---- the Model callbacks: glabcmcmc/examples/Mixture.py:5-53 ------------- */
+typedef enum glabc_sim_kind {
+    GLABC_SIM_ABS_GAUSS = 0        /* y = |theta| + noise, noise ~ DiagGaussian   Mixture.py:13-26 */
+} glabc_sim_kind;
+
+typedef struct glabc_model {
+    int32_t sim_kind;              /* glabc_sim_kind */
+    int32_t theta_dim;             /* Mixture.py:8  */
+    int32_t y_dim;                 /* Mixture.py:10 */
+    int32_t reserved;
+    glabc_dist prior;              /* prior_log_prob      Mixture.py:28-31 */
+    glabc_dist noise;              /* generate_samples    Mixture.py:19    */
+    float y_obs[GLABC_MAX_DIM];    /* discrepancy = ||y - y_obs||_2         Mixture.py:9,33-36 */
+    float kern_log_scale;          /* log(f32 epsilon)      calculate_log_kernel, Mixture.py:42-43 */
+    float kern_scale;              /* exp(log(f32 epsilon)) */
+    float kern_c0;                 /* f32(-0.5*log(2*pi))   */
+    float epsilon;                 /* epsilon itself (GLMALA.py:90 uses epsilon**2 in double) */
+} glabc_model;
+
+/* ---- chain state ----------------------------------------------------------- */
+#define GLABC_FLAG_LOCAL 1u        /* the reference's `local` dirty flag, GLMCMC.py:50,65,100 */
+
+typedef struct glabc_chains {
+    int64_t n_chains;              /* chains in this call (this GPU's shard) */
+    int64_t chain0;                /* global id of chain 0 of the shard (Philox counter words 0,1) */
+    int64_t stride;                /* elements between components, >= n_chains */
+    float* theta;                  /* [theta_dim][stride]  Theta_old  GLMCMC.py:48 */
+    float* y;                      /* [y_dim][stride]      y_old      GLMCMC.py:49 */
+    float* log_w;                  /* [stride] log_weight_old GLMCMC.py:53-55 (iSIR samplers; else NULL) */
+    uint32_t* flags;               /* [stride] GLABC_FLAG_* (iSIR samplers; else NULL) */
+    uint32_t* n_moves;             /* [stride] accepted moves, num_acc GLMCMC.py:51,88,101; NULL = not counted */
+} glabc_chains;
+
+/* Per-chain streaming sums for ESJD.py:17-24 and posterior moments, updated
+ * once per iteration inside the kernel (so a run needs no history to report
+ * them).  tri(d) = d(d+1)/2 entries, row-major upper triangle. */
+typedef struct glabc_moments {
+    double* sum_theta;             /* [theta_dim][stride]        sum_t theta_t            */
+    double* sum_outer;             /* [tri(theta_dim)][stride]   sum_t theta_t theta_t^T  */
+    double* sum_jump;              /* [tri(theta_dim)][stride]   sum_t (theta_t - theta_{t-1})(..)^T */
+} glabc_moments;
+
+/* Replayed random numbers (tests, common-random-number studies): when
+ * glabc_run.tape is non-NULL the kernel reads its draws from here instead of
+ * Philox.  Layout is chain-outermost, as recorded by tests/golden/make_golden.py. */
+typedef struct glabc_tape {
+    const float* u;                /* [n_chains][n_steps][2]  (branch, accept) f32 in [0,1) */
+    const double* r;               /* [n_chains][n_steps]     resampling uniform f64 in [0,1) */
+    const float* z;                /* [n_chains][n_steps][n_prop][theta_dim + y_dim] N(0,1) draws:
+                                      proposal noise then simulator noise; the local move uses row 0 */
+    int32_t n_prop;                /* rows per step on the tape */
+    int32_t reserved;
+} glabc_tape;
+
+typedef struct glabc_run {
+    uint64_t seed;                 /* Philox key */
+    uint32_t step0;                /* iteration index of the first step of this call (the reference's
+                                      loop variable i starts at 1: GLMCMC.py:58); Philox counter word 2 */
+    int32_t n_steps;               /* iterations fused into this launch (K) */
+    float global_frequency;        /* GLMCMC.py:59 */
+    int32_t batch_size;            /* iSIR proposals N, GLMCMC.py:66 (1..GLABC_MAX_BATCH); ignored by GlobalMCMC */
+    float* history;                /* NULL or [n_steps][theta_dim][hist_stride]: Theta_Re rows i=step0.. GLMCMC.py:89,104 */
+    int64_t hist_stride;           /* >= n_chains */
+    const glabc_moments* moments;  /* NULL or accumulators (same stride as chains) */
+    const glabc_tape* tape;        /* NULL = Philox */
+} glabc_run;
+
+/* ---- entry points ------------------------------------------------------------ */
+
+/* GLMCMC.py:58-104 -- iSIR global move with probability global_frequency,
+ * else random-walk MH local move.  `local` is the zero-mean increment
+ * distribution (GLMCMC.py:91), `importance` the absolute proposal (GLMCMC.py:66). */
+int glabc_glmcmc_steps(const glabc_model* model, const glabc_dist* local, const glabc_dist* importance,
+                       const glabc_chains* chains, const glabc_run* run, void* stream);
+
+/* GlobalMCMC.py:37-68 -- independence MH global move / random-walk MH local move. */
+int glabc_globalmcmc_steps(const glabc_model* model, const glabc_dist* local, const glabc_dist* global,
+                           const glabc_chains* chains, const glabc_run* run, void* stream);
+
+/* GLMCMC.py:52-55 -- (re)initialise log_w = prior + log-kernel - q(theta) and set
+ * GLABC_FLAG_LOCAL for every chain. */
+int glabc_init_weights(const glabc_model* model, const glabc_dist* importance,
+                       const glabc_chains* chains, void* stream);
+
+/* distribution.py:176-181 / 81-86 / 123-137: log_prob of n row-major points z[n][dim] -> out[n]. */
+int glabc_dist_log_prob(const glabc_dist* dist, const float* z, int64_t n, float* out, void* stream);
+
+/* Model callbacks on n row-major points (Mixture.py:28-45): used by the host
+ * mirror's Model class and by the parity tests. */
+int glabc_model_prior_log_prob(const glabc_model* model, const float* theta, int64_t n, float* out, void* stream);
+int glabc_model_discrepancy(const glabc_model* model, const float* y, int64_t n, float* out, void* stream);
+int glabc_model_log_kernel(const glabc_model* model, const float* y, int64_t n, float* out, void* stream);
+
+/* ESJD.py:2-25 for a batch of chains: history [n_rows][theta_dim][stride]
+ * (chain-major, as written by the samplers) -> esjd[n_chains] =
+ * det(D^T D / (n_rows-1))^(1/theta_dim), D = consecutive differences. */
+int glabc_esjd(const float* history, int64_t n_rows, int32_t theta_dim, int64_t n_chains, int64_t stride,
+               float* esjd_out, void* stream);
+
+/* The same quantity from the streamed jump sums (glabc_moments.sum_jump after n_steps
+ * iterations): esjd[c] = det(sum_jump_c / n_steps)^(1/theta_dim).  No history needed. */
+int glabc_moments_esjd(const glabc_moments* moments, int64_t n_steps, int32_t theta_dim, int64_t n_chains,
+                       int64_t stride, float* esjd_out, void* stream);
+
+int glabc_version(void);
+const char* glabc_status_string(int status);
+int glabc_last_hip_error(void);    /* hipError_t of the most recent failed launch on this thread */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLABC_H */

@@ -1,0 +1,179 @@
+/*
+ * glabc_numerics.h -- the numerical specification shared by every build of the
+ * GL-ABC-MCMC hot path: the counter-based random stream (Philox4x32-10), the
+ * u32 -> uniform / normal conversions, and the f32 elementary functions
+ * (exp, log, sin/cos of 2*pi*u) used inside a chain step.
+ *
+ * Why this is a header and not "whatever libm does": the accept / resample
+ * decisions of a chain must be bit-identical between the gfx950 kernel and the
+ * CPU checker (oracle/), so both sides evaluate the SAME sequence of IEEE-754
+ * operations: + - * / sqrt and fma, all correctly rounded on x86-64 and on
+ * CDNA4.  No hardware transcendental (v_exp_f32, v_log_f32, v_sin_f32) and no
+ * libm call appears below.  Every translation unit that includes this file
+ * must be compiled with  -ffp-contract=off  (contraction is spelled explicitly
+ * with fmaf where it is wanted).
+ *
+ * The reference (caofff/GL-ABC-MCMC) draws from torch's and NumPy's global
+ * Mersenne twisters (GLMCMC.py:17,59,66; distribution.py:167); a batched GPU
+ * sampler cannot share that stream, so the stream is re-specified here and
+ * parity with the reference is established on replayed random tapes instead
+ * (tests/golden/).
+ *
+ * Plain C99; also valid C++ and HIP device code.
+ */
+#ifndef GLABC_NUMERICS_H
+#define GLABC_NUMERICS_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GLABC_HD static __host__ __device__ __forceinline__
+#else
+#define GLABC_HD static inline
+#endif
+
+/* ---- bit casts ---------------------------------------------------------- */
+GLABC_HD uint32_t glabc_f2u(float x) { uint32_t u; __builtin_memcpy(&u, &x, 4); return u; }
+GLABC_HD float glabc_u2f(uint32_t u) { float x; __builtin_memcpy(&x, &u, 4); return x; }
+GLABC_HD uint64_t glabc_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
+GLABC_HD double glabc_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+
+/* ---- Philox4x32-10 (Salmon et al., SC'11; Random123 constants) ----------
+ * Stream layout used by every sampler:
+ *   key     = (seed_lo, seed_hi)                 -- uniform over a launch
+ *   counter = (chain_lo, chain_hi, step, slot)   -- per chain, per step, per draw
+ * so a chain's numbers depend only on (seed, global chain id, step, slot): not
+ * on launch geometry, steps-per-launch, or how chains are sharded over GPUs. */
+typedef struct { uint32_t v[4]; } glabc_u32x4;
+
+#define GLABC_PHILOX_M0 0xD2511F53u
+#define GLABC_PHILOX_M1 0xCD9E8D57u
+#define GLABC_PHILOX_W0 0x9E3779B9u
+#define GLABC_PHILOX_W1 0xBB67AE85u
+
+GLABC_HD glabc_u32x4 glabc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                         uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)GLABC_PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)GLABC_PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += GLABC_PHILOX_W0;
+        k1 += GLABC_PHILOX_W1;
+    }
+    glabc_u32x4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+/* ---- u32 -> uniform ------------------------------------------------------ */
+/* f32 uniform on [0,1): 24 random bits, the same grid torch.rand(float32) uses. */
+GLABC_HD float glabc_uniform_f32(uint32_t x) { return (float)(x >> 8) * 0x1p-24f; }
+/* f32 uniform on (0,1]: all 32 bits, never 0 (argument of log in Box-Muller). */
+GLABC_HD float glabc_uniform_pos_f32(uint32_t x) { return __builtin_fmaf((float)x, 0x1p-32f, 0x1p-33f); }
+/* f64 uniform on [0,1): 53 random bits, the grid numpy.random.uniform uses
+ * (the reference's resampling draw is a NumPy double, GLMCMC.py:17). */
+GLABC_HD double glabc_uniform_f64(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * 0x1p-53;
+}
+
+/* ---- f32 log ---------------------------------------------------------------
+ * x = 2^e * m, m in [sqrt(1/2), sqrt(2)); log m = f - f^2/2 + f^3 P(f), f = m-1.
+ * Max error < 1 ulp + rounding of the final sums (measured: tests/test_numerics.py). */
+GLABC_HD float glabc_logf(float x)
+{
+    uint32_t ix = glabc_f2u(x);
+    float escale = 0.0f;
+    if (ix == 0u || ix == 0x80000000u) return -__builtin_inff();        /* log(+-0) = -inf */
+    if (ix >> 31) return __builtin_nanf("");                             /* log(<0) = nan (nan with sign bit too) */
+    if (ix >= 0x7f800000u) return x;                                     /* +inf, nan */
+    if (ix < 0x00800000u) { x = x * 0x1p23f; ix = glabc_f2u(x); escale = -23.0f; }
+    ix += 0x3f800000u - 0x3f3504f3u;
+    float e = (float)((int32_t)(ix >> 23) - 127) + escale;
+    float m = glabc_u2f((ix & 0x007fffffu) + 0x3f3504f3u);
+    float f = m - 1.0f;
+    float p = -0x1.2d9544p-4f;
+    p = __builtin_fmaf(p, f, 0x1.0276dcp-3f);
+    p = __builtin_fmaf(p, f, -0x1.0e610cp-3f);
+    p = __builtin_fmaf(p, f, 0x1.235f0ep-3f);
+    p = __builtin_fmaf(p, f, -0x1.5467dap-3f);
+    p = __builtin_fmaf(p, f, 0x1.9998bp-3f);
+    p = __builtin_fmaf(p, f, -0x1.00023cp-2f);
+    p = __builtin_fmaf(p, f, 0x1.555564p-2f);
+    float f2 = f * f;
+    float r = __builtin_fmaf(p * f, f2, e * 0x1.7f7d1cp-20f);   /* f^3 P + e*ln2_lo */
+    r = __builtin_fmaf(-0.5f, f2, r);
+    r = r + f;
+    return __builtin_fmaf(e, 0x1.62e4p-1f, r);                  /* + e*ln2_hi (ln2_hi has 9 trailing zero bits: e*ln2_hi exact) */
+}
+
+/* ---- f32 exp ---------------------------------------------------------------
+ * x = k ln2 + r, |r| <= ln2/2; exp r = 1 + r + r^2 Q(r); result scaled by 2^k in
+ * two exact-or-once-rounded steps so the subnormal range rounds once. */
+GLABC_HD float glabc_expf(float x)
+{
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -104.0f) return 0.0f;
+    /* NaN falls through both tests and propagates through the arithmetic. */
+    float t = __builtin_fmaf(x, 0x1.715476p+0f, 12582912.0f);    /* round(x*log2e) in the low mantissa bits */
+    float k = t - 12582912.0f;
+    float r = __builtin_fmaf(k, -0x1.62e4p-1f, x);
+    r = __builtin_fmaf(k, -0x1.7f7d1cp-20f, r);
+    float q = 0x1.687bf6p-10f;
+    q = __builtin_fmaf(q, r, 0x1.123b9ep-7f);
+    q = __builtin_fmaf(q, r, 0x1.555b58p-5f);
+    q = __builtin_fmaf(q, r, 0x1.55548ep-3f);
+    q = __builtin_fmaf(q, r, 0x1.fffff8p-2f);
+    float p = __builtin_fmaf(q * r, r, r) + 1.0f;
+    int32_t ki = (int32_t)k;                            /* NaN -> unspecified int; p is NaN anyway */
+    int32_t k1 = ki / 2, k2 = ki - k1;
+    float s1 = glabc_u2f((uint32_t)(k1 + 127) << 23);
+    float s2 = glabc_u2f((uint32_t)(k2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+/* ---- sin, cos of 2*pi*u for u in [0,1) ---------------------------------------
+ * Quadrant reduction is exact (t = 4u, q = round(t), f = t-q in [-1/2,1/2]);
+ * then a = f*pi/2 and the usual degree-7 / degree-8 kernels on [-pi/4, pi/4]. */
+GLABC_HD void glabc_sincos2pi(float u, float* s_out, float* c_out)
+{
+    float t = u * 4.0f;
+    float qf = (t + 12582912.0f) - 12582912.0f;
+    float f = t - qf;
+    int32_t q = (int32_t)qf;
+    float a = f * 0x1.921fb6p+0f;
+    float z = a * a;
+    float sp = -0x1.993c46p-13f;
+    sp = __builtin_fmaf(sp, z, 0x1.11072p-7f);
+    sp = __builtin_fmaf(sp, z, -0x1.555544p-3f);
+    float s = __builtin_fmaf(sp * z, a, a);
+    float cp = 0x1.99f6ep-16f;
+    cp = __builtin_fmaf(cp, z, -0x1.6c0c5ep-10f);
+    cp = __builtin_fmaf(cp, z, 0x1.55554ap-5f);
+    float c = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    float ss = (q & 1) ? c : s;
+    float cc = (q & 1) ? s : c;
+    if (q & 2) ss = -ss;
+    if ((q + 1) & 2) cc = -cc;
+    *s_out = ss;
+    *c_out = cc;
+}
+
+/* ---- two standard normals from two u32 (Box-Muller) ------------------------- */
+GLABC_HD void glabc_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1)
+{
+    float u1 = glabc_uniform_pos_f32(a);
+    float rad = __builtin_sqrtf(-2.0f * glabc_logf(u1));
+    float s, c;
+    glabc_sincos2pi(glabc_uniform_f32(b), &s, &c);
+    *z0 = rad * c;
+    *z1 = rad * s;
+}
+
+#endif /* GLABC_NUMERICS_H */

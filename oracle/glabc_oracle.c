@@ -1,0 +1,662 @@
+/*
+ * glabc_oracle.c -- CPU restatement of the reference's hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; nothing under
+ * gl-abc-mcmc_amd/ links, imports or calls it.
+ *
+ * What it is: a scalar, one-chain-at-a-time, plain-C restatement of the
+ * reference's sampler loops, following the reference's float32 operation order
+ * line by line (citations on each function, paths relative to /root/reference).
+ * It is pinned against the reference itself: tests/golden/make_golden.py
+ * imports the reference's Python modules in the build container, replays a
+ * recorded random-number tape through the UNMODIFIED reference loops, and
+ * stores tape + resulting chains under tests/golden/; tests/test_oracle_golden.py
+ * replays the same tapes through this file and requires bit-identical chains.
+ *
+ * Random numbers come either from a tape (glabc_run.tape, the pinning mode)
+ * or from the Philox stream specified in include/glabc_numerics.h (the mode in
+ * which the gfx950 kernels are compared against this file, bit for bit).
+ *
+ * The elementary functions exp/log are those of include/glabc_numerics.h (the
+ * numerical specification shared with the device code), not libm and not
+ * ATen's vectorised ones; they differ from ATen's in the last bit for ~1 % of
+ * arguments, which can only change a chain through an accept/resample
+ * near-tie (|log u - log_acc| within an ulp): none occurs in the goldens.
+ *
+ * Build: oracle/Makefile  ->  oracle/libglabc_oracle.so
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../include/glabc.h"
+#include "../include/glabc_numerics.h"
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* ATen's float32 sum over a contiguous row of n elements, as this torch build
+ * (2.10, CPU) associates it -- probed in the build container, see DESIGN.md
+ * "row-sum order".  n < 8: four scalar lanes, leftovers into lane 0, lanes
+ * combined left to right.  n >= 8: the same four-lane scheme over 8-wide
+ * vectors, then a scalar accumulator takes the n%8 tail in order and finally
+ * the 8 vector partials in order.  Matters because the reference normalises
+ * the N+1 iSIR weights with torch.sum (GLMCMC.py:82). */
+static float aten_rowsum_f32(const float* x, int n)
+{
+    if (n <= 0) return 0.0f;
+    if (n < 8) {
+        int g = n / 4;
+        if (g == 0) {
+            float s = x[0];
+            for (int i = 1; i < n; ++i) s = s + x[i];
+            return s;
+        }
+        float l0 = x[0], l1 = x[1], l2 = x[2], l3 = x[3];
+        for (int i = 4; i < n; ++i) l0 = l0 + x[i];     /* g == 1 here: all leftovers go to lane 0 */
+        return ((l0 + l1) + l2) + l3;
+    }
+    int nv = n / 8;
+    float acc[8];
+    {
+        int g = nv / 4;
+        if (g == 0) {
+            for (int k = 0; k < 8; ++k) acc[k] = x[k];
+            for (int v = 1; v < nv; ++v)
+                for (int k = 0; k < 8; ++k) acc[k] = acc[k] + x[8 * v + k];
+        } else {
+            float l[4][8];
+            for (int q = 0; q < 4; ++q)
+                for (int k = 0; k < 8; ++k) l[q][k] = x[8 * q + k];
+            for (int i = 1; i < g; ++i)
+                for (int q = 0; q < 4; ++q)
+                    for (int k = 0; k < 8; ++k) l[q][k] = l[q][k] + x[8 * (4 * i + q) + k];
+            for (int v = 4 * g; v < nv; ++v)
+                for (int k = 0; k < 8; ++k) l[0][k] = l[0][k] + x[8 * v + k];
+            for (int k = 0; k < 8; ++k) acc[k] = ((l[0][k] + l[1][k]) + l[2][k]) + l[3][k];
+        }
+    }
+    float fa = 0.0f;
+    for (int i = 8 * nv; i < n; ++i) fa = fa + x[i];
+    for (int k = 0; k < 8; ++k) fa = fa + acc[k];
+    return fa;
+}
+
+ORACLE_API float oracle_aten_rowsum_f32(const float* x, int n) { return aten_rowsum_f32(x, n); }
+
+/* ------------------------------------------------------------------------- */
+/* distribution.py */
+
+/* DiagGaussian.log_prob, distribution.py:176-181:
+ *   log_p = -0.5*d*log(2pi) - sum_j( log_scale_j + 0.5 * ((z_j - loc_j)/exp(log_scale_j))^2 ) */
+static float diag_gauss_log_prob(const glabc_dist* g, const float* z)
+{
+    float t[GLABC_MAX_DIM];
+    for (int j = 0; j < g->dim; ++j) {
+        float e = (z[j] - g->p0[j]) / g->p2[j];
+        t[j] = g->p1[j] + 0.5f * (e * e);
+    }
+    return g->c0 - aten_rowsum_f32(t, g->dim);
+}
+
+/* DiagGaussian.forward given its noise, distribution.py:166-174:
+ *   z = loc + exp(log_scale)*eps ;  log_p = C - sum_j( log_scale_j + 0.5*eps_j^2 ) */
+static float diag_gauss_forward(const glabc_dist* g, const float* eps, float* z)
+{
+    float t[GLABC_MAX_DIM];
+    for (int j = 0; j < g->dim; ++j) {
+        z[j] = g->p0[j] + g->p2[j] * eps[j];
+        t[j] = g->p1[j] + 0.5f * (eps[j] * eps[j]);
+    }
+    return g->c0 - aten_rowsum_f32(t, g->dim);
+}
+
+/* Uniform.log_prob, distribution.py:81-86: constant, -inf outside the CLOSED box. */
+static float uniform_log_prob(const glabc_dist* g, const float* z)
+{
+    for (int j = 0; j < g->dim; ++j)
+        if (z[j] < g->p0[j] || z[j] > g->p1[j]) return -INFINITY;
+    return g->c0;
+}
+
+/* Uniform.forward given its [0,1) draws, distribution.py:73-79: z = low + (high-low)*u. */
+static float uniform_forward(const glabc_dist* g, const float* u, float* z)
+{
+    for (int j = 0; j < g->dim; ++j) z[j] = g->p0[j] + g->p2[j] * u[j];
+    return g->c0;
+}
+
+static int dist_log_prob(const glabc_dist* g, const float* z, float* out)
+{
+    switch (g->kind) {
+    case GLABC_DIST_DIAG_GAUSS: *out = diag_gauss_log_prob(g, z); return 0;
+    case GLABC_DIST_UNIFORM: *out = uniform_log_prob(g, z); return 0;
+    default: return GLABC_ERR_KIND;
+    }
+}
+
+ORACLE_API int oracle_dist_log_prob(const glabc_dist* dist, const float* z, int64_t n, float* out)
+{
+    if (!dist || !z || !out) return GLABC_ERR_NULL;
+    if (dist->dim < 1 || dist->dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    for (int64_t i = 0; i < n; ++i) {
+        int rc = dist_log_prob(dist, z + i * dist->dim, out + i);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* forward() with the noise supplied by the caller: noise[n][dim] -> z[n][dim], log_p[n]. */
+ORACLE_API int oracle_dist_forward(const glabc_dist* dist, const float* noise, int64_t n, float* z, float* log_p)
+{
+    if (!dist || !noise || !z || !log_p) return GLABC_ERR_NULL;
+    if (dist->dim < 1 || dist->dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    for (int64_t i = 0; i < n; ++i) {
+        if (dist->kind == GLABC_DIST_DIAG_GAUSS)
+            log_p[i] = diag_gauss_forward(dist, noise + i * dist->dim, z + i * dist->dim);
+        else if (dist->kind == GLABC_DIST_UNIFORM)
+            log_p[i] = uniform_forward(dist, noise + i * dist->dim, z + i * dist->dim);
+        else
+            return GLABC_ERR_KIND;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* examples/Mixture.py -- the Model callbacks */
+
+/* generate_samples for one theta and one simulation, Mixture.py:19-23:
+ *   y = |theta| + (loc + exp(log_scale)*eps) */
+static void model_simulate(const glabc_model* m, const float* theta, const float* eps, float* y)
+{
+    for (int j = 0; j < m->y_dim; ++j) {
+        float noise = m->noise.p0[j] + m->noise.p2[j] * eps[j];
+        y[j] = fabsf(theta[j]) + noise;
+    }
+}
+
+/* prior_log_prob, Mixture.py:28-31 */
+static float model_prior(const glabc_model* m, const float* theta)
+{
+    float v = 0.0f;
+    dist_log_prob(&m->prior, theta, &v);
+    return v;
+}
+
+/* discrepancy, Mixture.py:33-36: sqrt(sum_j (y_j - y_obs_j)^2) */
+static float model_discrepancy(const glabc_model* m, const float* y)
+{
+    float t[GLABC_MAX_DIM];
+    for (int j = 0; j < m->y_dim; ++j) {
+        float d = y[j] - m->y_obs[j];
+        t[j] = d * d;
+    }
+    return sqrtf(aten_rowsum_f32(t, m->y_dim));
+}
+
+/* calculate_log_kernel, Mixture.py:38-45: DiagGaussian(1, 0, log eps).log_prob(dis) */
+static float model_log_kernel_dis(const glabc_model* m, float dis)
+{
+    float e = (dis - 0.0f) / m->kern_scale;
+    return m->kern_c0 - (m->kern_log_scale + 0.5f * (e * e));
+}
+
+static float model_log_kernel(const glabc_model* m, const float* y)
+{
+    return model_log_kernel_dis(m, model_discrepancy(m, y));
+}
+
+static int model_check(const glabc_model* m)
+{
+    if (!m) return GLABC_ERR_NULL;
+    if (m->sim_kind != GLABC_SIM_ABS_GAUSS) return GLABC_ERR_KIND;
+    if (m->theta_dim < 1 || m->theta_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    if (m->y_dim < 1 || m->y_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    if (m->y_dim != m->theta_dim) return GLABC_ERR_DIM;        /* |theta| + noise is elementwise */
+    if (m->prior.dim != m->theta_dim || m->noise.dim != m->y_dim) return GLABC_ERR_DIM;
+    if (m->noise.kind != GLABC_DIST_DIAG_GAUSS) return GLABC_ERR_KIND;
+    return 0;
+}
+
+ORACLE_API int oracle_model_prior_log_prob(const glabc_model* m, const float* theta, int64_t n, float* out)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i) out[i] = model_prior(m, theta + i * m->theta_dim);
+    return 0;
+}
+
+ORACLE_API int oracle_model_discrepancy(const glabc_model* m, const float* y, int64_t n, float* out)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i) out[i] = model_discrepancy(m, y + i * m->y_dim);
+    return 0;
+}
+
+ORACLE_API int oracle_model_log_kernel(const glabc_model* m, const float* y, int64_t n, float* out)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i) out[i] = model_log_kernel(m, y + i * m->y_dim);
+    return 0;
+}
+
+/* generate_samples with the noise supplied: theta[n][d], eps[n][y_dim] -> y[n][y_dim] */
+ORACLE_API int oracle_model_simulate(const glabc_model* m, const float* theta, const float* eps, int64_t n, float* y)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i) model_simulate(m, theta + i * m->theta_dim, eps + i * m->y_dim, y + i * m->y_dim);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* the random draws of one iteration of one chain */
+
+typedef struct step_draws {
+    float u_branch;                                 /* torch.rand(1)            GLMCMC.py:59 */
+    float u_accept;                                 /* torch.rand(1)            GLMCMC.py:98 */
+    double u_resample;                              /* np.random.uniform(0,1)   GLMCMC.py:17 */
+    float z[GLABC_MAX_BATCH][2 * GLABC_MAX_DIM];    /* per proposal: d proposal draws then y_dim simulator draws */
+} step_draws;
+
+/* Philox slots of one (chain, step): slot 0 = {branch, accept, resample hi, resample lo};
+ * proposal j uses slots 1 + j*spp .. , spp = ceil((d + y_dim)/4) blocks, consecutive u32 pairs
+ * feeding Box-Muller (DiagGaussian proposal) or single u32 -> [0,1) (Uniform proposal) for the
+ * first d draws; simulator draws are always normal. */
+static void draws_from_philox(step_draws* s, uint64_t seed, uint64_t chain, uint32_t step, int n_prop, int d, int yd,
+                              int prop_uniform)
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)chain, c1 = (uint32_t)(chain >> 32);
+    glabc_u32x4 h = glabc_philox4x32_10(c0, c1, step, 0u, k0, k1);
+    s->u_branch = glabc_uniform_f32(h.v[0]);
+    s->u_accept = glabc_uniform_f32(h.v[1]);
+    s->u_resample = glabc_uniform_f64(h.v[2], h.v[3]);
+    int m = d + yd;
+    int spp = (m + 3) / 4;
+    for (int j = 0; j < n_prop; ++j) {
+        uint32_t w[4 * ((2 * GLABC_MAX_DIM + 3) / 4)];
+        for (int b = 0; b < spp; ++b) {
+            glabc_u32x4 r = glabc_philox4x32_10(c0, c1, step, (uint32_t)(1 + j * spp + b), k0, k1);
+            for (int q = 0; q < 4; ++q) w[4 * b + q] = r.v[q];
+        }
+        /* normals are made in pairs from words (2i, 2i+1); a pair may straddle the
+         * proposal/simulator boundary when d is odd */
+        float nrm[4 * ((2 * GLABC_MAX_DIM + 3) / 4)];
+        for (int i = 0; 2 * i < 4 * spp; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
+        for (int i = 0; i < m; ++i) s->z[j][i] = nrm[i];
+        if (prop_uniform)
+            for (int i = 0; i < d; ++i) s->z[j][i] = glabc_uniform_f32(w[i]);
+    }
+}
+
+static void draws_from_tape(step_draws* s, const glabc_tape* t, int64_t chain_local, int64_t t_idx, int64_t n_steps,
+                            int n_prop, int d, int yd)
+{
+    int64_t ct = chain_local * n_steps + t_idx;
+    s->u_branch = t->u[2 * ct + 0];
+    s->u_accept = t->u[2 * ct + 1];
+    s->u_resample = t->r ? t->r[ct] : 0.0;
+    int m = d + yd;
+    for (int j = 0; j < n_prop && j < t->n_prop; ++j)
+        for (int i = 0; i < m; ++i) s->z[j][i] = t->z[(ct * t->n_prop + j) * m + i];
+}
+
+/* ------------------------------------------------------------------------- */
+/* a proposal (global) or increment (local) distribution applied to its noise */
+
+static int prop_forward(const glabc_dist* g, const float* noise, float* z, float* log_p)
+{
+    if (g->kind == GLABC_DIST_DIAG_GAUSS) { *log_p = diag_gauss_forward(g, noise, z); return 0; }
+    if (g->kind == GLABC_DIST_UNIFORM) { *log_p = uniform_forward(g, noise, z); return 0; }
+    return GLABC_ERR_KIND;
+}
+
+typedef struct chain_state {
+    float theta[GLABC_MAX_DIM];
+    float y[GLABC_MAX_DIM];
+    float log_w;
+    uint32_t flags;
+    uint32_t n_moves;
+} chain_state;
+
+static void load_chain(chain_state* s, const glabc_chains* c, int64_t i, int d, int yd)
+{
+    for (int j = 0; j < d; ++j) s->theta[j] = c->theta[j * c->stride + i];
+    for (int j = 0; j < yd; ++j) s->y[j] = c->y[j * c->stride + i];
+    s->log_w = c->log_w ? c->log_w[i] : 0.0f;
+    s->flags = c->flags ? c->flags[i] : 0u;
+    s->n_moves = c->n_moves ? c->n_moves[i] : 0u;
+}
+
+static void store_chain(const chain_state* s, const glabc_chains* c, int64_t i, int d, int yd)
+{
+    for (int j = 0; j < d; ++j) c->theta[j * c->stride + i] = s->theta[j];
+    for (int j = 0; j < yd; ++j) c->y[j * c->stride + i] = s->y[j];
+    if (c->log_w) c->log_w[i] = s->log_w;
+    if (c->flags) c->flags[i] = s->flags;
+    if (c->n_moves) c->n_moves[i] = s->n_moves;
+}
+
+static void record(const glabc_run* run, const glabc_chains* c, int64_t i, int64_t t, int d, const float* theta,
+                   const float* theta_prev)
+{
+    if (run->history)
+        for (int j = 0; j < d; ++j) run->history[(t * d + j) * run->hist_stride + i] = theta[j];
+    if (run->moments) {
+        const glabc_moments* m = run->moments;
+        int k = 0;
+        for (int a = 0; a < d; ++a) {
+            m->sum_theta[a * c->stride + i] += (double)theta[a];
+            for (int b = a; b < d; ++b, ++k) {
+                m->sum_outer[k * c->stride + i] += (double)theta[a] * (double)theta[b];
+                double da = (double)theta[a] - (double)theta_prev[a];
+                double db = (double)theta[b] - (double)theta_prev[b];
+                m->sum_jump[k * c->stride + i] += da * db;
+            }
+        }
+    }
+}
+
+static int run_check(const glabc_model* m, const glabc_dist* a, const glabc_dist* b, const glabc_chains* c,
+                     const glabc_run* r)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    if (!a || !b || !c || !r) return GLABC_ERR_NULL;
+    if (!c->theta || !c->y) return GLABC_ERR_NULL;
+    if (a->dim != m->theta_dim || b->dim != m->theta_dim) return GLABC_ERR_DIM;
+    if (c->n_chains < 0 || c->stride < c->n_chains || r->n_steps < 0) return GLABC_ERR_ARG;
+    if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
+    return 0;
+}
+
+/* the random-walk MH local move shared by GLMCMC.py:90-104 and GlobalMCMC.py:55-68:
+ *   theta' = Local_Proposal.sample(1) + theta ; y' = simulate(theta')
+ *   log_acc = prior(theta') + K(y') - prior(theta) - K(y)     (left to right)
+ *   accept iff log(u) < log_acc */
+static int local_move(const glabc_model* m, const glabc_dist* local, chain_state* s, const step_draws* dr)
+{
+    int d = m->theta_dim, yd = m->y_dim;
+    float inc[GLABC_MAX_DIM], th[GLABC_MAX_DIM], y[GLABC_MAX_DIM], lq;
+    prop_forward(local, dr->z[0], inc, &lq);
+    for (int j = 0; j < d; ++j) th[j] = inc[j] + s->theta[j];
+    model_simulate(m, th, dr->z[0] + d, y);
+    float log_acc = ((model_prior(m, th) + model_log_kernel(m, y)) - model_prior(m, s->theta)) - model_log_kernel(m, s->y);
+    float log_u = glabc_logf(dr->u_accept);
+    if (log_u < log_acc) {
+        memcpy(s->theta, th, sizeof(float) * d);
+        memcpy(s->y, y, sizeof(float) * yd);
+        return 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* GLMCMC.py:24-137 */
+
+/* log_weight_old, GLMCMC.py:53-55 / 62-64 */
+static float isir_weight_of_state(const glabc_model* m, const glabc_dist* imp, const chain_state* s)
+{
+    float lq = 0.0f;
+    dist_log_prob(imp, s->theta, &lq);
+    return (model_prior(m, s->theta) + model_log_kernel(m, s->y)) - lq;
+}
+
+/* the iSIR global move, GLMCMC.py:60-88 (same body at GLMALA.py:152-179) */
+static int isir_move(const glabc_model* m, const glabc_dist* imp, int N, chain_state* s, const step_draws* dr)
+{
+    int d = m->theta_dim, yd = m->y_dim;
+    float th[GLABC_MAX_BATCH + 1][GLABC_MAX_DIM], y[GLABC_MAX_BATCH + 1][GLABC_MAX_DIM];
+    float lw[GLABC_MAX_BATCH + 1], w[GLABC_MAX_BATCH + 1];
+    if (s->flags & GLABC_FLAG_LOCAL) s->log_w = isir_weight_of_state(m, imp, s);    /* :60-64 */
+    s->flags &= ~GLABC_FLAG_LOCAL;                                                  /* :65 */
+    memcpy(th[0], s->theta, sizeof(float) * d);
+    memcpy(y[0], s->y, sizeof(float) * yd);
+    lw[0] = s->log_w;
+    int n = 1;
+    for (int j = 0; j < N; ++j) {
+        float lq;
+        prop_forward(imp, dr->z[j], th[n], &lq);                                    /* :66 */
+        int has_nan = 0;
+        for (int k = 0; k < d; ++k) has_nan |= isnan(th[n][k]);
+        if (has_nan) continue;                                                      /* :67-70 */
+        model_simulate(m, th[n], dr->z[j] + d, y[n]);                               /* :71 */
+        lw[n] = (model_prior(m, th[n]) + model_log_kernel(m, y[n])) - lq;           /* :72-74 */
+        ++n;
+    }
+    for (int k = 0; k < n; ++k) {
+        w[k] = glabc_expf(lw[k]);                                                   /* :78 */
+        if (isnan(w[k])) w[k] = 0.0f;                                               /* :80-81 */
+    }
+    float tot = aten_rowsum_f32(w, n);                                              /* :82 */
+    for (int k = 0; k < n; ++k) w[k] = w[k] / tot;
+    /* weight_sampling, GLMCMC.py:7-22: python-float (double) running sum of the float32
+     * weights, first j with ran < s; falls off the end -> None -> the chain stays (:84). */
+    int ind = -1;
+    double acc = 0.0;
+    for (int k = 0; k < n; ++k) {
+        acc += (double)w[k];
+        if (dr->u_resample < acc) { ind = k; break; }
+    }
+    if (ind > 0) {                                                                  /* :84-88 */
+        memcpy(s->theta, th[ind], sizeof(float) * d);
+        memcpy(s->y, y[ind], sizeof(float) * yd);
+        s->log_w = lw[ind];
+        return 1;
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_init_weights(const glabc_model* m, const glabc_dist* imp, const glabc_chains* c)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    if (!imp || !c || !c->theta || !c->y || !c->log_w || !c->flags) return GLABC_ERR_NULL;
+    for (int64_t i = 0; i < c->n_chains; ++i) {
+        chain_state s;
+        load_chain(&s, c, i, m->theta_dim, m->y_dim);
+        s.log_w = isir_weight_of_state(m, imp, &s);
+        s.flags |= GLABC_FLAG_LOCAL;                                                /* GLMCMC.py:50 */
+        store_chain(&s, c, i, m->theta_dim, m->y_dim);
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_glmcmc_steps(const glabc_model* m, const glabc_dist* local, const glabc_dist* imp,
+                                   const glabc_chains* c, const glabc_run* run)
+{
+    int rc = run_check(m, local, imp, c, run);
+    if (rc) return rc;
+    if (!c->log_w || !c->flags) return GLABC_ERR_NULL;
+    int N = run->batch_size;
+    if (N < 1 || N > GLABC_MAX_BATCH) return GLABC_ERR_ARG;
+    int d = m->theta_dim, yd = m->y_dim;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < c->n_chains; ++i) {
+        chain_state s;
+        step_draws dr;
+        memset(&dr, 0, sizeof dr);
+        load_chain(&s, c, i, d, yd);
+        for (int64_t t = 0; t < run->n_steps; ++t) {
+            float prev[GLABC_MAX_DIM];
+            memcpy(prev, s.theta, sizeof(float) * d);
+            /* Both proposal kinds draw from the same slots; the global move's noise kind
+             * follows the importance proposal, the local move's follows the local one. */
+            if (run->tape)
+                draws_from_tape(&dr, run->tape, i, t, run->n_steps, N, d, yd);
+            else
+                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, N, d, yd, 0);
+            if (dr.u_branch < run->global_frequency) {                              /* GLMCMC.py:59 */
+                if (!run->tape && imp->kind == GLABC_DIST_UNIFORM)
+                    draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, N, d, yd, 1);
+                s.n_moves += (uint32_t)isir_move(m, imp, N, &s, &dr);
+            } else {
+                if (!run->tape && local->kind == GLABC_DIST_UNIFORM)
+                    draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, yd, 1);
+                if (local_move(m, local, &s, &dr)) {
+                    s.flags |= GLABC_FLAG_LOCAL;                                    /* :100 */
+                    s.n_moves += 1u;
+                }
+            }
+            record(run, c, i, t, d, s.theta, prev);                                 /* :89,104 */
+        }
+        store_chain(&s, c, i, d, yd);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* GlobalMCMC.py:6-98 */
+
+/* independence MH global move, GlobalMCMC.py:39-53:
+ *   log_acc = prior' + K' + q(theta) - q' - prior - K     (left to right) */
+static int independence_move(const glabc_model* m, const glabc_dist* glob, chain_state* s, const step_draws* dr)
+{
+    int d = m->theta_dim, yd = m->y_dim;
+    float th[GLABC_MAX_DIM], y[GLABC_MAX_DIM], lq_new, lq_old = 0.0f;
+    prop_forward(glob, dr->z[0], th, &lq_new);
+    model_simulate(m, th, dr->z[0] + d, y);
+    dist_log_prob(glob, s->theta, &lq_old);
+    float log_acc = ((((model_prior(m, th) + model_log_kernel(m, y)) + lq_old) - lq_new) - model_prior(m, s->theta)) -
+                    model_log_kernel(m, s->y);
+    float log_u = glabc_logf(dr->u_accept);
+    if (log_u < log_acc) {
+        memcpy(s->theta, th, sizeof(float) * d);
+        memcpy(s->y, y, sizeof(float) * yd);
+        return 1;
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_globalmcmc_steps(const glabc_model* m, const glabc_dist* local, const glabc_dist* glob,
+                                       const glabc_chains* c, const glabc_run* run)
+{
+    int rc = run_check(m, local, glob, c, run);
+    if (rc) return rc;
+    int d = m->theta_dim, yd = m->y_dim;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < c->n_chains; ++i) {
+        chain_state s;
+        step_draws dr;
+        memset(&dr, 0, sizeof dr);
+        load_chain(&s, c, i, d, yd);
+        for (int64_t t = 0; t < run->n_steps; ++t) {
+            float prev[GLABC_MAX_DIM];
+            memcpy(prev, s.theta, sizeof(float) * d);
+            if (run->tape)
+                draws_from_tape(&dr, run->tape, i, t, run->n_steps, 1, d, yd);
+            else
+                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, yd, 0);
+            int is_global = dr.u_branch < run->global_frequency;                    /* GlobalMCMC.py:39 */
+            const glabc_dist* p = is_global ? glob : local;
+            if (!run->tape && p->kind == GLABC_DIST_UNIFORM)
+                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, yd, 1);
+            int moved = is_global ? independence_move(m, glob, &s, &dr) : local_move(m, local, &s, &dr);
+            s.n_moves += (uint32_t)moved;
+            record(run, c, i, t, d, s.theta, prev);                                 /* :53,68 */
+        }
+        store_chain(&s, c, i, d, yd);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* ESJD.py:2-25 : det( D^T D / (n-1) )^(1/d), D = consecutive differences, all float32.
+ * torch.det is an LU with partial pivoting; restated for d <= GLABC_MAX_DIM.
+ * history is chain-major [n_rows][d][stride] as the samplers write it. */
+ORACLE_API int oracle_esjd(const float* history, int64_t n_rows, int32_t d, int64_t n_chains, int64_t stride,
+                           float* out)
+{
+    if (!history || !out) return GLABC_ERR_NULL;
+    if (d < 1 || d > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    if (n_rows < 2) return GLABC_ERR_ARG;
+    for (int64_t c = 0; c < n_chains; ++c) {
+        float a[GLABC_MAX_DIM][GLABC_MAX_DIM];
+        memset(a, 0, sizeof a);
+        for (int64_t t = 1; t < n_rows; ++t) {
+            float dl[GLABC_MAX_DIM];
+            for (int j = 0; j < d; ++j)
+                dl[j] = history[(t * d + j) * stride + c] - history[((t - 1) * d + j) * stride + c];
+            for (int p = 0; p < d; ++p)
+                for (int q = 0; q < d; ++q) a[p][q] += dl[p] * dl[q];
+        }
+        float nd = (float)(n_rows - 1);
+        for (int p = 0; p < d; ++p)
+            for (int q = 0; q < d; ++q) a[p][q] = a[p][q] / nd;
+        float det = 1.0f;
+        for (int k = 0; k < d; ++k) {
+            int piv = k;
+            for (int r = k + 1; r < d; ++r)
+                if (fabsf(a[r][k]) > fabsf(a[piv][k])) piv = r;
+            if (piv != k) {
+                for (int q = 0; q < d; ++q) { float tmp = a[k][q]; a[k][q] = a[piv][q]; a[piv][q] = tmp; }
+                det = -det;
+            }
+            det *= a[k][k];
+            if (a[k][k] == 0.0f) break;
+            for (int r = k + 1; r < d; ++r) {
+                float f = a[r][k] / a[k][k];
+                for (int q = k; q < d; ++q) a[r][q] -= f * a[k][q];
+            }
+        }
+        out[c] = powf(det, 1.0f / (float)d);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* numerics hooks for tests/test_numerics.py */
+
+ORACLE_API void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    glabc_u32x4 r = glabc_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+
+ORACLE_API void oracle_expf_v(const float* x, int64_t n, float* out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = glabc_expf(x[i]);
+}
+
+ORACLE_API void oracle_logf_v(const float* x, int64_t n, float* out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = glabc_logf(x[i]);
+}
+
+ORACLE_API void oracle_sincos2pi_v(const float* u, int64_t n, float* s, float* c)
+{
+    for (int64_t i = 0; i < n; ++i) glabc_sincos2pi(u[i], s + i, c + i);
+}
+
+ORACLE_API void oracle_normal_pair_v(const uint32_t* a, const uint32_t* b, int64_t n, float* z0, float* z1)
+{
+    for (int64_t i = 0; i < n; ++i) glabc_normal_pair(a[i], b[i], z0 + i, z1 + i);
+}
+
+ORACLE_API void oracle_uniforms_v(const uint32_t* a, const uint32_t* b, int64_t n, float* u, float* upos, double* u64)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        u[i] = glabc_uniform_f32(a[i]);
+        upos[i] = glabc_uniform_pos_f32(a[i]);
+        u64[i] = glabc_uniform_f64(a[i], b[i]);
+    }
+}
+
+/* the draws of one (chain, step) exactly as the samplers consume them */
+ORACLE_API void oracle_step_draws(uint64_t seed, uint64_t chain, uint32_t step, int n_prop, int d, int yd,
+                                  float* u2, double* r, float* z)
+{
+    step_draws dr;
+    memset(&dr, 0, sizeof dr);
+    draws_from_philox(&dr, seed, chain, step, n_prop, d, yd, 0);
+    u2[0] = dr.u_branch;
+    u2[1] = dr.u_accept;
+    *r = dr.u_resample;
+    for (int j = 0; j < n_prop; ++j)
+        for (int i = 0; i < d + yd; ++i) z[j * (d + yd) + i] = dr.z[j][i];
+}

@@ -1,0 +1,350 @@
+"""Generate the golden fixtures of tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (it imports /root/reference); the GPU box and
+the test-suite see only the .npz files this script writes.  Usage:
+
+    python tests/golden/make_golden.py            # all fixtures (~5 min)
+    python tests/golden/make_golden.py primitives # one group
+
+How the reference is driven
+  * its modules are imported as they lie in /root/reference (an empty package
+    object named `glabcmcmc` with __path__ pointing there lets `import
+    glabcmcmc.GLMCMC` etc. work without executing the package's __init__, which
+    would pull in the third-party `normflows` that is not installed here);
+  * `torch.rand`, `torch.randn` and `np.random.uniform` are replaced, for the
+    duration of one run, by functions that hand out pre-computed numbers in the
+    order the loops ask for them (a "tape"); the loops themselves
+    (GLMCMC.py:58-104, GlobalMCMC.py:37-68) run unmodified, one chain at a time;
+  * "philox" fixtures compute the tape from the Philox stream specified in
+    include/glabc_numerics.h (through the oracle library's oracle_step_draws),
+    so only seeds and the resulting chains are stored and BOTH the CPU oracle
+    and the gfx950 kernels can be compared with the reference bit for bit;
+    "tape" fixtures use NumPy-generated numbers and store the tape as well.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "gl-abc-mcmc_amd")]
+sys.dont_write_bytecode = True
+
+REF = "/root/reference"
+pkg = types.ModuleType("glabcmcmc")
+pkg.__path__ = [os.path.join(REF, "glabcmcmc")]
+sys.modules["glabcmcmc"] = pkg
+sys.path.insert(0, os.path.join(REF, "glabcmcmc", "examples"))
+
+import glabcmcmc.distribution as rdist          # noqa: E402
+import glabcmcmc.GLMCMC as rglmcmc              # noqa: E402
+import glabcmcmc.GlobalMCMC as rglobal          # noqa: E402
+import glabcmcmc.ESJD as resjd                  # noqa: E402
+from Mixture import Mixture_set                 # noqa: E402
+
+import oracle_lib                               # noqa: E402
+
+torch.set_num_threads(1)
+
+
+# --------------------------------------------------------------------------- tape
+class Tape:
+    """Numbers for one chain: u[T,2] (branch, accept), r[T] f64, z[T,P,d+yd]."""
+
+    def __init__(self, u, r, z, d, gf, isir):
+        self.u, self.r, self.z, self.d, self.gf, self.isir = u, r, z, d, gf, isir
+        self.t = -1
+        self.expect = "branch"
+        self.k = 0
+
+    def rand(self, *size, **kw):
+        if len(size) == 1 and isinstance(size[0], (tuple, list)):
+            size = tuple(size[0])
+        if len(size) == 2:                          # Uniform.forward: rand((n, d))
+            return self._noise(size)
+        assert size == (1,), size
+        if self.expect == "branch":
+            self.t += 1
+            self.k = 0
+            v = self.u[self.t, 0]
+            if not (self.isir and v < self.gf):
+                self.expect = "accept"
+        else:
+            v = self.u[self.t, 1]
+            self.expect = "branch"
+        return torch.tensor([v], dtype=torch.float32)
+
+    def _noise(self, shape):
+        n, dd = shape
+        lo = 0 if self.k == 0 else self.d
+        out = self.z[self.t, :n, lo:lo + dd]
+        self.k += 1
+        return torch.from_numpy(np.ascontiguousarray(out))
+
+    def randn(self, *size, **kw):
+        if len(size) == 1 and isinstance(size[0], (tuple, list)):
+            size = tuple(size[0])
+        return self._noise(size)
+
+    def uniform(self, lo=0, hi=1):
+        return float(self.r[self.t])
+
+
+@contextlib.contextmanager
+def patched(tape):
+    saved = (torch.rand, torch.randn, np.random.uniform)
+    torch.rand, torch.randn, np.random.uniform = tape.rand, tape.randn, tape.uniform
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            yield
+    finally:
+        torch.rand, torch.randn, np.random.uniform = saved
+
+
+def make_dist(spec):
+    kind = spec[0]
+    if kind == "gauss":
+        _, loc, scale = spec
+        return rdist.DiagGaussian(len(loc), torch.tensor(loc, dtype=torch.float32),
+                                  torch.log(torch.tensor(scale, dtype=torch.float32)))
+    if kind == "uniform":
+        _, low, high = spec
+        return rdist.Uniform(len(low), torch.tensor(low, dtype=torch.float32), torch.tensor(high, dtype=torch.float32))
+    raise ValueError(kind)
+
+
+def philox_tape(L, seed, chain, T, P, d, yd, uniform_prop_global, uniform_prop_local, gf):
+    """Draws of steps 1..T of one chain from the specified Philox stream."""
+    u = np.zeros((T, 2), np.float32)
+    r = np.zeros(T, np.float64)
+    z = np.zeros((T, P, d + yd), np.float32)
+    u2 = np.zeros(2, np.float32)
+    rr = np.zeros(1, np.float64)
+    zz = np.zeros((P, d + yd), np.float32)
+    w = np.zeros(4, np.uint32)
+    for t in range(T):
+        L.oracle_step_draws(seed, chain, t + 1, P, d, yd, u2.ctypes.data, rr.ctypes.data, zz.ctypes.data)
+        u[t], r[t], z[t] = u2, rr[0], zz
+        is_global = u2[0] < np.float32(gf)
+        if (uniform_prop_global and is_global) or (uniform_prop_local and not is_global):
+            # a Uniform proposal takes the raw words of its slots as [0,1) uniforms
+            spp = (d + yd + 3) // 4
+            key = np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)
+            for j in range(P):
+                words = []
+                for b in range(spp):
+                    ctr = np.array([chain & 0xFFFFFFFF, chain >> 32, t + 1, 1 + j * spp + b], np.uint32)
+                    L.oracle_philox4x32_10(ctr.ctypes.data, key.ctypes.data, w.ctypes.data)
+                    words += list(w)
+                z[t, j, :d] = (np.array(words[:d], np.uint32) >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+    return u, r, z
+
+
+def numpy_tape(rng, T, P, d, yd, uniform_prop):
+    u = (rng.integers(0, 1 << 24, (T, 2)).astype(np.float32) * np.float32(2.0 ** -24))
+    r = rng.random(T)
+    z = rng.standard_normal((T, P, d + yd)).astype(np.float32)
+    if uniform_prop:
+        z[:, :, :d] = rng.integers(0, 1 << 24, (T, P, d)).astype(np.float32) * np.float32(2.0 ** -24)
+    return u, r, z
+
+
+def run_reference(algo, cfg, theta0, y0, tape):
+    model = Mixture_set(cfg["epsilon"])
+    local = make_dist(cfg["local"])
+    glob = make_dist(cfg["global"])
+    T = cfg["T"]
+    th0 = torch.from_numpy(theta0.copy())
+    yy0 = torch.from_numpy(y0.copy()).view(1, -1)
+    with patched(tape):
+        if algo == "glmcmc":
+            out = rglmcmc.GLMCMC(model, T + 1, th0, yy0, local, None, cfg["gf"], glob, cfg["N"])
+        else:
+            out = rglobal.GlobalMCMC(model, T + 1, th0, yy0, glob, None, cfg["gf"], local)
+    assert tape.t == T - 1, (tape.t, T)
+    return out.numpy().copy()
+
+
+def sampler_fixture(name, algo, cfg, mode):
+    L = oracle_lib.load()
+    d = yd = 2
+    C, T, N = cfg["C"], cfg["T"], cfg["N"]
+    P = N if algo == "glmcmc" else 1
+    rng = np.random.default_rng(cfg["seed"] + 1000)
+    theta0 = (rng.standard_normal((C, d)) * cfg.get("theta0_sd", 0.0)).astype(np.float32)
+    y0 = (np.abs(theta0) + np.sqrt(np.float32(0.05)) * rng.standard_normal((C, yd)).astype(np.float32)).astype(np.float32)
+    ug = cfg["global"][0] == "uniform"
+    ul = cfg["local"][0] == "uniform"
+    chains = np.zeros((T + 1, C, d), np.float32)
+    tapes = []
+    for c in range(C):
+        if mode == "philox":
+            u, r, z = philox_tape(L, cfg["seed"], cfg.get("chain0", 0) + c, T, P, d, yd, ug, ul, cfg["gf"])
+        else:
+            assert ug == ul
+            u, r, z = numpy_tape(rng, T, P, d, yd, ug)
+            tapes.append((u, r, z))
+        tape = Tape(u, r, z, d, np.float32(cfg["gf"]), algo == "glmcmc")
+        chains[:, c, :] = run_reference(algo, cfg, theta0[c], y0[c], tape)
+        print("\r%s chain %d/%d" % (name, c + 1, C), end="", flush=True)
+    print()
+    out = dict(algo=algo, mode=mode, theta0=theta0, y0=y0, chains=chains,
+               cfg=np.array(repr(cfg)))
+    if mode == "tape":
+        out["tape_u"] = np.stack([t[0] for t in tapes])
+        out["tape_r"] = np.stack([t[1] for t in tapes])
+        out["tape_z"] = np.stack([t[2] for t in tapes])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    moves = (np.abs(np.diff(chains, axis=0)).sum(-1) > 0).sum(0)
+    print("   moves/chain: mean %.1f min %d max %d" % (moves.mean(), moves.min(), moves.max()))
+
+
+G2 = lambda s: ("gauss", [0.0, 0.0], [s, s])          # noqa: E731
+
+SAMPLER_FIXTURES = {
+    # BASELINE config 2's algorithm and parameters (examples/Mixture.py:67-73)
+    "glmcmc_philox_bench": ("glmcmc", dict(epsilon=0.05, gf=0.9, N=5, C=96, T=1500, seed=20261003,
+                                           local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    # wider kernel -> many moves; N=8 exercises the >=8-element torch.sum order
+    "glmcmc_philox_n8": ("glmcmc", dict(epsilon=0.3, gf=0.5, N=8, C=24, T=600, seed=77, chain0=5000000000,
+                                        theta0_sd=1.0, local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    "glmcmc_philox_n1": ("glmcmc", dict(epsilon=0.3, gf=0.6, N=1, C=16, T=400, seed=3,
+                                        theta0_sd=1.0, local=G2(0.5), **{"global": G2(1.2)}), "philox"),
+    "glmcmc_philox_n3": ("glmcmc", dict(epsilon=0.2, gf=0.8, N=3, C=16, T=400, seed=4,
+                                        theta0_sd=1.0, local=G2(0.35), **{"global": ("gauss", [0.5, -0.25], [1.5, 0.75])}), "philox"),
+    "glmcmc_philox_n16": ("glmcmc", dict(epsilon=0.3, gf=0.9, N=16, C=12, T=300, seed=5,
+                                         theta0_sd=1.0, local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    "glmcmc_philox_uniform": ("glmcmc", dict(epsilon=0.3, gf=0.7, N=4, C=16, T=500, seed=6, theta0_sd=1.0,
+                                             local=("uniform", [-0.5, -0.5], [0.5, 0.5]),
+                                             **{"global": ("uniform", [-3.0, -3.0], [3.0, 3.0])}), "philox"),
+    # BASELINE config 1's algorithm (GlobalMCMC, gf 0.5)
+    "globalmcmc_philox_bench": ("globalmcmc", dict(epsilon=0.05, gf=0.5, N=1, C=48, T=2000, seed=11,
+                                                   local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    "globalmcmc_philox_wide": ("globalmcmc", dict(epsilon=0.3, gf=0.5, N=1, C=16, T=600, seed=12, theta0_sd=1.0,
+                                                  local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    # stored-tape fixtures (NumPy numbers; independent of the Philox specification)
+    "glmcmc_tape_small": ("glmcmc", dict(epsilon=0.2, gf=0.8, N=5, C=8, T=300, seed=21, theta0_sd=1.0,
+                                         local=G2(0.35), **{"global": G2(1.0)}), "tape"),
+    "globalmcmc_tape_small": ("globalmcmc", dict(epsilon=0.2, gf=0.5, N=1, C=8, T=300, seed=22, theta0_sd=1.0,
+                                                 local=G2(0.35), **{"global": G2(1.0)}), "tape"),
+}
+
+
+# --------------------------------------------------------------------------- primitives
+def primitives():
+    rng = np.random.default_rng(5)
+    out = {}
+    # DiagGaussian.log_prob / forward (distribution.py:166-181)
+    for tag, loc, scale in (("std", [0.0, 0.0], [1.0, 1.0]), ("lp", [0.0, 0.0], [0.35, 0.35]),
+                            ("gen", [0.5, -0.25], [1.5, 0.75]), ("d1", [0.0], [0.05]),
+                            ("d4", [0.1, -0.2, 0.3, 0.0], [0.5, 1.0, 2.0, 0.1]),
+                            ("d7", [0.0] * 7, [1.0, 0.5, 0.25, 2.0, 1.5, 0.75, 0.3]),
+                            ("d8", [0.1] * 8, [1.0, 0.5, 0.25, 2.0, 1.5, 0.75, 0.3, 0.9])):
+        g = make_dist(("gauss", loc, scale))
+        d = len(loc)
+        z = (rng.standard_normal((257, d)) * 2).astype(np.float32)
+        eps = rng.standard_normal((257, d)).astype(np.float32)
+        out["dg_%s_loc" % tag] = np.array(loc, np.float32)
+        out["dg_%s_log_scale" % tag] = g.log_scale.numpy()
+        out["dg_%s_scale" % tag] = torch.exp(g.log_scale).numpy()
+        out["dg_%s_z" % tag] = z
+        out["dg_%s_log_prob" % tag] = g.log_prob(torch.from_numpy(z)).numpy()
+        saved = torch.randn
+        torch.randn = lambda *a, **k: torch.from_numpy(eps)
+        try:
+            zz, lp = g.forward(257)
+        finally:
+            torch.randn = saved
+        out["dg_%s_eps" % tag] = eps
+        out["dg_%s_fwd_z" % tag] = zz.numpy()
+        out["dg_%s_fwd_log_p" % tag] = lp.numpy()
+    # Uniform (distribution.py:50-86)
+    for tag, low, high in (("box", [-3.0, -3.0], [3.0, 3.0]), ("inc", [-0.5, -0.5], [0.5, 0.5]),
+                           ("d4", [0.0] * 4, [10.0] * 4)):
+        g = make_dist(("uniform", low, high))
+        d = len(low)
+        z = (rng.uniform(-1.2, 1.2, (200, d)) * np.abs(np.array(high))).astype(np.float32)
+        z[0] = np.array(low, np.float32)             # closed interval: the bounds are inside
+        z[1] = np.array(high, np.float32)
+        u = rng.integers(0, 1 << 24, (200, d)).astype(np.float32) * np.float32(2.0 ** -24)
+        out["un_%s_low" % tag] = np.array(low, np.float32)
+        out["un_%s_high" % tag] = np.array(high, np.float32)
+        out["un_%s_log_prob_val" % tag] = np.float32(g.log_prob_val.item())
+        out["un_%s_z" % tag] = z
+        out["un_%s_log_prob" % tag] = g.log_prob(torch.from_numpy(z)).numpy()
+        saved = torch.rand
+        torch.rand = lambda *a, **k: torch.from_numpy(u)
+        try:
+            zz, lp = g.forward(200)
+        finally:
+            torch.rand = saved
+        out["un_%s_u" % tag] = u
+        out["un_%s_fwd_z" % tag] = zz.numpy()
+        out["un_%s_fwd_log_p" % tag] = lp.numpy()
+    out["un_default_log_prob_val"] = np.float32(rdist.Uniform(2).log_prob_val.item())
+    # Mixture_set callbacks (examples/Mixture.py:13-45)
+    for eps_k in (0.05, 0.3):
+        m = Mixture_set(eps_k)
+        tag = "mix_%g" % eps_k
+        theta = (rng.standard_normal((300, 2)) * 1.5).astype(np.float32)
+        noise = rng.standard_normal((300, 2)).astype(np.float32)
+        saved = torch.randn
+        torch.randn = lambda *a, **k: torch.from_numpy(noise)
+        try:
+            y = m.generate_samples(torch.from_numpy(theta), 1).numpy()
+        finally:
+            torch.randn = saved
+        out[tag + "_theta"] = theta
+        out[tag + "_noise"] = noise
+        out[tag + "_y"] = y
+        out[tag + "_prior"] = m.prior_log_prob(torch.from_numpy(theta)).numpy()
+        out[tag + "_dis"] = m.discrepancy(torch.from_numpy(y)).numpy()
+        out[tag + "_logk"] = m.calculate_log_kernel(torch.from_numpy(y)).numpy()
+        out[tag + "_noise_scale"] = torch.exp(torch.log(torch.tensor([0.05, 0.05]).sqrt())).numpy()
+        out[tag + "_noise_log_scale"] = torch.log(torch.tensor([0.05, 0.05]).sqrt()).numpy()
+        out[tag + "_kern_log_scale"] = torch.log(torch.tensor([eps_k])).numpy()
+        out[tag + "_kern_scale"] = torch.exp(torch.log(torch.tensor([eps_k]))).numpy()
+    # esjd (ESJD.py:2-25)
+    chains = []
+    vals = []
+    for T, d in ((5, 2), (300, 2), (2000, 2), (300, 4), (50, 1), (400, 3)):
+        x = np.cumsum((rng.random((T, d)) < 0.2) * rng.standard_normal((T, d)), axis=0).astype(np.float32)
+        chains.append(x)
+        vals.append(float(resjd.esjd(torch.from_numpy(x))))
+    out["esjd_known"] = np.float32(resjd.esjd(torch.tensor([[0, 0], [1, 0], [1, 2], [1, 2], [0, 1.0]])))
+    for i, (x, v) in enumerate(zip(chains, vals)):
+        out["esjd_chain_%d" % i] = x
+        out["esjd_value_%d" % i] = np.float32(v)
+    # torch.sum association (GLMCMC.py:82): rows of n = 2..17 float32 weights
+    for n in range(1, 18):
+        x = (rng.standard_normal((64, n)) * rng.choice([1e-3, 1.0, 1e3], (64, n))).astype(np.float32)
+        out["rowsum_%d_x" % n] = x
+        out["rowsum_%d_sum" % n] = np.array([torch.sum(torch.from_numpy(r)).item() for r in x], np.float32)
+    # weight_sampling edge cases (GLMCMC.py:7-22)
+    ws = []
+    for w, ran in (([0.2, 0.3, 0.5], 0.0), ([0.2, 0.3, 0.5], 0.19999), ([0.2, 0.3, 0.5], 0.2), ([0.2, 0.3, 0.5], 0.999999),
+                   ([0.0, 0.0, 1.0], 0.5), ([0.5, 0.25], 0.9), ([float("nan"), 0.5], 0.1), ([1.0], 0.3)):
+        saved = np.random.uniform
+        np.random.uniform = lambda a, b, ran=ran: ran
+        try:
+            ind = rglmcmc.weight_sampling(list(map(float, w)))
+        finally:
+            np.random.uniform = saved
+        ws.append((w, ran, -1 if ind is None else ind))
+    out["weight_sampling_cases"] = np.array(repr(ws))
+    np.savez_compressed(os.path.join(HERE, "primitives.npz"), **out)
+    print("primitives: %d arrays" % len(out))
+
+
+if __name__ == "__main__":
+    want = sys.argv[1:]
+    if not want or "primitives" in want:
+        primitives()
+    for name, (algo, cfg, mode) in SAMPLER_FIXTURES.items():
+        if not want or name in want or algo in want:
+            sampler_fixture(name, algo, cfg, mode)

@@ -1,0 +1,46 @@
+"""Shared helpers for the tests: golden loading and descriptor construction."""
+import os
+
+import numpy as np
+import torch
+
+from glabcmcmc_amd import distribution
+from glabcmcmc_amd.examples.Mixture import Mixture_set
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as f:
+        g = {k: f[k] for k in f.files}
+    if "cfg" in g:
+        g["cfg"] = eval(str(g["cfg"]), {"__builtins__": {}}, {"dict": dict})     # repr() of a plain dict
+    return g
+
+
+def make_dist(spec):
+    """('gauss', loc, scale) / ('uniform', low, high) -> host-mirror distribution object"""
+    kind = spec[0]
+    if kind == "gauss":
+        return distribution.DiagGaussian(len(spec[1]), torch.tensor(spec[1], dtype=torch.float32),
+                                         torch.log(torch.tensor(spec[2], dtype=torch.float32)))
+    if kind == "uniform":
+        return distribution.Uniform(len(spec[1]), torch.tensor(spec[1], dtype=torch.float32),
+                                    torch.tensor(spec[2], dtype=torch.float32))
+    raise ValueError(kind)
+
+
+def descriptors(cfg):
+    model = Mixture_set(cfg["epsilon"]).descriptor()
+    return model, make_dist(cfg["local"]).descriptor(), make_dist(cfg["global"]).descriptor()
+
+
+SAMPLER_GOLDENS = [
+    "glmcmc_philox_bench", "glmcmc_philox_n8", "glmcmc_philox_n1", "glmcmc_philox_n3", "glmcmc_philox_n16",
+    "glmcmc_philox_uniform", "globalmcmc_philox_bench", "globalmcmc_philox_wide",
+    "glmcmc_tape_small", "globalmcmc_tape_small",
+]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)

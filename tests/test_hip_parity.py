@@ -1,0 +1,317 @@
+"""Parity of the gfx950 kernels (through the C ABI) with
+  (1) the reference itself -- the golden chains produced by the unmodified reference loops
+      on the specified Philox stream (tests/golden/*_philox_*.npz), bit for bit;
+  (2) the CPU oracle on fresh seeded inputs -- histories, final states, counters, bit for bit;
+  (3) size-independent properties at BASELINE.json's full size (65 536 chains).
+GPU only:  python -m pytest tests -m gpu
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib
+from helpers import SAMPLER_GOLDENS, bits, descriptors, load_golden, make_dist
+
+pytestmark = pytest.mark.gpu
+
+ENTRY = {"glmcmc": "glabc_glmcmc_steps", "globalmcmc": "glabc_globalmcmc_steps"}
+
+
+def hip_run(algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=0, steps_per_launch=None, moments=False,
+            step0=1, chains=None, history=True):
+    from glabcmcmc_amd import engine
+    dev = torch.device("cuda", 0)
+    if chains is None:
+        chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0)
+        if algo == "glmcmc":
+            engine.init_weights(model, glob, chains)
+    hist = torch.empty(T, chains.d, chains.n, dtype=torch.float32, device=dev) if history else None
+    mom = engine.Moments(chains.n, chains.d, dev) if moments else None
+    engine.run_steps(ENTRY[algo], model, local, glob, chains, T, step0, seed, gf, N, history=hist, moments=mom,
+                     steps_per_launch=steps_per_launch)
+    torch.cuda.synchronize()
+    return (hist.cpu().numpy() if history else None), chains, mom
+
+
+def oracle_run(oracle, algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=0, moments=False):
+    hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
+    hh = np.zeros((T, theta0.shape[1], theta0.shape[0]), np.float32)
+    mom = oracle_lib.HostMoments(theta0.shape[0], theta0.shape[1]) if moments else None
+    run, keep = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh, moments=mom)
+    cs = hc.struct()
+    if algo == "glmcmc":
+        assert oracle.oracle_init_weights(C.byref(model), C.byref(glob), C.byref(cs)) == 0
+        rc = oracle.oracle_glmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    else:
+        rc = oracle.oracle_globalmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    assert rc == 0
+    return hh, hc, mom
+
+
+def assert_same_state(chains, hc, isir):
+    assert np.array_equal(bits(chains.theta.cpu().numpy()), bits(hc.theta))
+    assert np.array_equal(bits(chains.y.cpu().numpy()), bits(hc.y))
+    assert np.array_equal(chains.n_moves.cpu().numpy().astype(np.uint32), hc.n_moves)
+    if isir:
+        assert np.array_equal(bits(chains.log_w.cpu().numpy()), bits(hc.log_w))
+        assert np.array_equal(chains.flags.cpu().numpy().astype(np.uint32), hc.flags)
+
+
+# ---------------------------------------------------------------------------------- (1)
+@pytest.mark.parametrize("name", [n for n in SAMPLER_GOLDENS if "philox" in n])
+def test_hip_reproduces_reference_chains(hip, name):
+    """The kernel, on the Philox stream, visits exactly the float32 states the unmodified
+    reference loop visited when it was fed the same stream."""
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, local, glob = descriptors(cfg)
+    hist, chains, _ = hip_run(str(g["algo"]), model, local, glob, g["theta0"], g["y0"], cfg["T"], cfg["seed"],
+                              cfg["gf"], cfg["N"], chain0=cfg.get("chain0", 0))
+    got = np.concatenate([g["theta0"][None], hist.transpose(0, 2, 1)], axis=0)
+    same = bits(got) == bits(g["chains"])
+    assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
+
+
+# ---------------------------------------------------------------------------------- (2)
+CASES = [
+    # algo, d, N, gf, eps, local, global, chains, T
+    ("glmcmc", 2, 5, 0.9, 0.05, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1]), 4096, 300),
+    ("glmcmc", 2, 5, 0.5, 0.3, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1]), 1000, 257),
+    ("glmcmc", 2, 1, 0.3, 0.3, ("gauss", [0, 0], [0.5, 0.5]), ("gauss", [0.2, -0.1], [1.5, 0.7]), 777, 200),
+    ("glmcmc", 2, 2, 1.0, 0.3, ("gauss", [0, 0], [0.5, 0.5]), ("gauss", [0, 0], [1, 1]), 640, 100),
+    ("glmcmc", 2, 7, 0.0, 0.3, ("gauss", [0, 0], [0.5, 0.5]), ("gauss", [0, 0], [1, 1]), 640, 100),
+    ("glmcmc", 2, 8, 0.8, 0.2, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1]), 512, 150),
+    ("glmcmc", 2, 16, 0.8, 0.2, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1]), 512, 100),
+    ("glmcmc", 2, 4, 0.7, 0.3, ("uniform", [-0.5, -0.5], [0.5, 0.5]), ("uniform", [-3, -3], [3, 3]), 1024, 200),
+    ("glmcmc", 2, 3, 0.6, 0.3, ("gauss", [0, 0], [0.35, 0.35]), ("uniform", [-3, -3], [3, 3]), 1024, 200),
+    ("globalmcmc", 2, 1, 0.5, 0.05, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1]), 4096, 300),
+    ("globalmcmc", 2, 1, 0.5, 0.3, ("uniform", [-0.5, -0.5], [0.5, 0.5]), ("gauss", [0, 0], [1, 1]), 1000, 200),
+    ("globalmcmc", 2, 1, 1.0, 0.3, ("gauss", [0, 0], [0.35, 0.35]), ("uniform", [-3, -3], [3, 3]), 640, 100),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-N%d-gf%g-%s-%s" % (c[0], c[2], c[3], c[5][0], c[6][0]))
+def test_hip_equals_oracle(hip, oracle, case):
+    algo, d, N, gf, eps, lspec, gspec, n, T = case
+    cfg = dict(epsilon=eps, local=lspec, **{"global": gspec})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(n * 31 + T)
+    theta0 = rng.standard_normal((n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    hist, chains, mom = hip_run(algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True)
+    hh, hc, hm = oracle_run(oracle, algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True)
+    same = bits(hist) == bits(hh)
+    assert same.all(), "first mismatch at (t, dim, chain) = %s" % (np.argwhere(~same)[0],)
+    assert_same_state(chains, hc, algo == "glmcmc")
+    assert hc.n_moves.sum() > 0
+    # streamed moments: same float64 operations in the same order on both sides
+    assert np.array_equal(mom.sum_theta.cpu().numpy(), hm.sum_theta)
+    assert np.array_equal(mom.sum_outer.cpu().numpy(), hm.sum_outer)
+    assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
+
+
+@pytest.mark.parametrize("d", [1, 3, 4])
+def test_other_dimensions(hip, oracle, d):
+    """theta_dim 1, 3, 4 (the Model is |theta| + noise in any dimension)."""
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import distribution
+    prior = distribution.DiagGaussian(d, torch.zeros(d), torch.zeros(d)).descriptor()
+    noise = distribution.DiagGaussian(d, torch.zeros(d), torch.log(torch.full((d,), 0.05).sqrt())).descriptor()
+    kern = distribution.DiagGaussian(1, torch.tensor([0.0]), torch.log(torch.tensor([0.3]))).descriptor()
+    model = A.Model()
+    model.sim_kind, model.theta_dim, model.y_dim = A.SIM_ABS_GAUSS, d, d
+    model.prior, model.noise = prior, noise
+    for j in range(d):
+        model.y_obs[j] = 1.5 - 0.25 * j
+    model.kern_log_scale, model.kern_scale, model.kern_c0, model.epsilon = kern.p1[0], kern.p2[0], kern.c0, 0.3
+    local = make_dist(("gauss", [0.0] * d, [0.35] * d)).descriptor()
+    glob = make_dist(("gauss", [0.1 * j for j in range(d)], [1.0 + 0.1 * j for j in range(d)])).descriptor()
+    rng = np.random.default_rng(d)
+    n, T, N = 1030, 150, 5
+    theta0 = rng.standard_normal((n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
+    for algo in ("glmcmc", "globalmcmc"):
+        hist, chains, _ = hip_run(algo, model, local, glob, theta0, y0, T, 99 + d, 0.6, N)
+        hh, hc, _ = oracle_run(oracle, algo, model, local, glob, theta0, y0, T, 99 + d, 0.6, N)
+        assert np.array_equal(bits(hist), bits(hh))
+        assert_same_state(chains, hc, algo == "glmcmc")
+        assert hc.n_moves.sum() > 0
+
+
+def test_launch_geometry_and_sharding_invariance(hip):
+    """Results do not depend on iterations-per-launch nor on how chains are split over
+    calls / GPUs: two shards with chain0 offsets equal one big call (the multi-GPU contract)."""
+    cfg = dict(epsilon=0.3, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(5)
+    n, T, N, seed = 3000, 120, 5, 424242
+    theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, 2))).astype(np.float32)
+    ref, c_ref, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, seed, 0.8, N, chain0=10)
+    a, c_a, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, seed, 0.8, N, chain0=10, steps_per_launch=7)
+    assert np.array_equal(bits(a), bits(ref))
+    assert np.array_equal(bits(c_a.log_w.cpu().numpy()), bits(c_ref.log_w.cpu().numpy()))
+    k = 1111
+    s0, _, _ = hip_run("glmcmc", model, local, glob, theta0[:k], y0[:k], T, seed, 0.8, N, chain0=10)
+    s1, _, _ = hip_run("glmcmc", model, local, glob, theta0[k:], y0[k:], T, seed, 0.8, N, chain0=10 + k)
+    assert np.array_equal(bits(np.concatenate([s0, s1], axis=2)), bits(ref))
+    other, _, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, seed + 1, 0.8, N, chain0=10)
+    assert not np.array_equal(other, ref)
+
+
+def test_empty_and_ragged_inputs(hip):
+    cfg = dict(epsilon=0.3, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(6)
+    for n in (1, 63, 65):                       # not multiples of the wavefront
+        theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+        y0 = np.abs(theta0).astype(np.float32)
+        hist, chains, _ = hip_run("glmcmc", model, local, glob, theta0, y0, 40, 3, 0.8, 5)
+        assert hist.shape == (40, 2, n) and np.isfinite(hist).all()
+    # zero iterations: state untouched
+    theta0 = rng.standard_normal((10, 2)).astype(np.float32)
+    _, chains, _ = hip_run("glmcmc", model, local, glob, theta0, np.abs(theta0), 0, 3, 0.8, 5, history=False)
+    assert np.array_equal(chains.theta.cpu().numpy().T, theta0)
+
+
+def test_bad_arguments_are_refused(hip):
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import engine
+    cfg = dict(epsilon=0.3, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.zeros(8, 2), torch.zeros(8, 2), dev)
+    cs = chains.struct()
+
+    def call(m=model, lo=local, g=glob, c=cs, **kw):
+        run = A.Run()
+        run.seed, run.step0, run.n_steps, run.global_frequency, run.batch_size = 1, 1, 4, 0.5, 5
+        for k, v in kw.items():
+            setattr(run, k, v)
+        return hip.glabc_glmcmc_steps(C.byref(m), C.byref(lo), C.byref(g), C.byref(c), C.byref(run), None)
+
+    assert call() == 0
+    assert call(batch_size=0) == -4 and call(batch_size=17) == -4 and call(n_steps=-1) == -4
+    bad = make_dist(("gauss", [0, 0], [1, 1])).descriptor()
+    bad.p2[0] = float("nan")
+    assert call(g=bad) == -4
+    bad3 = make_dist(("gauss", [0, 0, 0], [1, 1, 1])).descriptor()
+    assert call(g=bad3) == -2
+    nul = chains.struct()
+    nul.theta = None
+    assert call(c=nul) == -1
+    assert hip.glabc_status_string(-4) == b"bad argument"
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------- primitives
+@pytest.fixture(scope="module")
+def prim():
+    return load_golden("primitives")
+
+
+def test_distribution_log_prob_on_gpu(hip, prim):
+    from glabcmcmc_amd import distribution
+    for tag in ("std", "lp", "gen", "d1", "d4", "d7", "d8"):
+        loc = torch.from_numpy(prim["dg_%s_loc" % tag])
+        g = distribution.DiagGaussian(len(loc), loc, torch.from_numpy(prim["dg_%s_log_scale" % tag]))
+        out = g.log_prob(torch.from_numpy(prim["dg_%s_z" % tag]).cuda()).cpu().numpy()
+        assert np.array_equal(bits(out), bits(prim["dg_%s_log_prob" % tag])), tag
+    for tag in ("box", "inc", "d4"):
+        g = distribution.Uniform(len(prim["un_%s_low" % tag]), torch.from_numpy(prim["un_%s_low" % tag]),
+                                 torch.from_numpy(prim["un_%s_high" % tag]))
+        out = g.log_prob(torch.from_numpy(prim["un_%s_z" % tag]).cuda()).cpu().numpy()
+        assert np.array_equal(bits(out), bits(prim["un_%s_log_prob" % tag])), tag
+
+
+@pytest.mark.parametrize("eps", [0.05, 0.3])
+def test_model_callbacks_on_gpu(hip, oracle, prim, eps):
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    m = Mixture_set(eps)
+    tag = "mix_%g" % eps
+    theta = torch.from_numpy(prim[tag + "_theta"]).cuda()
+    y = torch.from_numpy(prim[tag + "_y"]).cuda()
+    assert np.array_equal(bits(m.prior_log_prob(theta).cpu().numpy()), bits(prim[tag + "_prior"]))
+    desc = m.descriptor()
+    n = y.shape[0]
+    o = np.empty(n, np.float32)
+    yy = prim[tag + "_y"]
+    assert oracle.oracle_model_discrepancy(C.byref(desc), yy.ctypes.data, n, o.ctypes.data) == 0
+    assert np.array_equal(bits(m.discrepancy(y).cpu().numpy()), bits(o))
+    assert oracle.oracle_model_log_kernel(C.byref(desc), yy.ctypes.data, n, o.ctypes.data) == 0
+    got = m.calculate_log_kernel(y).cpu().numpy()
+    assert np.array_equal(bits(got), bits(o))
+    ref = prim[tag + "_logk"]
+    assert np.all(np.abs(got - ref) <= 4e-7 * np.maximum(np.abs(ref), 1.0))
+
+
+def test_esjd_kernel(hip, oracle, prim):
+    from glabcmcmc_amd import esjd
+    i = 0
+    while "esjd_chain_%d" % i in prim:
+        x = prim["esjd_chain_%d" % i]
+        if x.shape[1] <= 4:
+            ref = prim["esjd_value_%d" % i]
+            got = esjd(torch.from_numpy(x))
+            assert got.shape == () and got.dtype == np.float32
+            assert abs(got - ref) <= 2e-5 * abs(ref), (i, got, ref)
+        i += 1
+    assert esjd(torch.tensor([[0, 0], [1, 0], [1, 2], [1, 2], [0, 1.0]])) == np.float32(0.75)
+
+
+def test_esjd_from_history_equals_streamed_moments(hip):
+    from glabcmcmc_amd.ESJD import esjd_per_chain
+    cfg = dict(epsilon=0.3, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(8)
+    n, T = 2048, 400
+    theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+    y0 = np.abs(theta0).astype(np.float32)
+    hist, chains, mom = hip_run("glmcmc", model, local, glob, theta0, y0, T, 17, 0.8, 5, moments=True)
+    full = torch.from_numpy(np.concatenate([theta0.T[None], hist], axis=0)).cuda()
+    a = esjd_per_chain(full).cpu().numpy()
+    b = mom.esjd().cpu().numpy()
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-9)
+    assert (a > 0).mean() > 0.9
+
+
+# ---------------------------------------------------------------------------------- (3)
+def test_full_size_bit_parity_and_posterior(hip, oracle):
+    """BASELINE config 2 at full width: 65 536 chains, GLMCMC iSIR N=5, gf 0.9, eps 0.05.
+    (a) the first 150 iterations of ALL chains equal the CPU oracle bit for bit;
+    (b) after burn-in the pooled posterior moments match the analytic ABC posterior
+        (|theta_i| ~ N(1.425178, 0.049881)) and ESJD from streamed
+        moments equals ESJD from the recorded history within 1e-3."""
+    from glabcmcmc_amd.ESJD import esjd_per_chain
+    cfg = dict(epsilon=0.05, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    n, N, gf, seed = 65536, 5, 0.9, 20261003
+    rng = np.random.default_rng(1)
+    theta0 = np.zeros((n, 2), np.float32)
+    y0 = (0.2236068 * rng.standard_normal((n, 2))).astype(np.float32)
+    T0 = 150
+    hist, chains, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T0, seed, gf, N)
+    hh, hc, _ = oracle_run(oracle, "glmcmc", model, local, glob, theta0, y0, T0, seed, gf, N)
+    assert np.array_equal(bits(hist), bits(hh))
+    assert_same_state(chains, hc, True)
+    # burn in (no history), then 1500 recorded iterations with streamed moments
+    hip_run("glmcmc", model, local, glob, None, None, 2350, seed, gf, N, chains=chains, step0=1 + T0, history=False)
+    start = chains.theta.clone()
+    T1 = 1500
+    hist, chains, mom = hip_run("glmcmc", model, local, glob, None, None, T1, seed, gf, N, chains=chains,
+                                step0=1 + T0 + 2350, moments=True)
+    mean_abs = np.abs(hist).mean()
+    mean_sq = (hist.astype(np.float64) ** 2).mean()
+    assert abs(mean_abs - 1.425178) / 1.425178 < 2e-3, mean_abs
+    assert abs(mean_sq - 2.081014) / 2.081014 < 3e-3, mean_sq
+    assert abs(hist.mean()) < 0.02                                    # four symmetric modes
+    sq = mom.second_moment().cpu().numpy()
+    assert abs((sq[:, 0, 0].mean() + sq[:, 1, 1].mean()) / 2 - mean_sq) / mean_sq < 1e-6
+    full = torch.cat([start[None], torch.from_numpy(hist).cuda()], dim=0)
+    e_hist = esjd_per_chain(full).cpu().numpy().astype(np.float64)
+    e_mom = mom.esjd().cpu().numpy().astype(np.float64)
+    assert abs(e_hist.mean() - e_mom.mean()) / e_hist.mean() < 1e-3
+    assert 0.001 < e_hist.mean() < 1.0

@@ -1,0 +1,165 @@
+"""The CPU oracle (oracle/glabc_oracle.c) against the golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from glabcmcmc_amd import _capi as A
+from helpers import SAMPLER_GOLDENS, bits, descriptors, load_golden
+
+# The oracle's exp/log are those of include/glabc_numerics.h, ATen's are its own vectorised
+# ones; densities agree to a few float32 ulp of the largest term, not bit for bit.
+LOGP_RTOL = 4e-7
+
+
+def _close(a, b, scale=None):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin)
+    assert np.array_equal(a[~fin], b[~fin])
+    s = np.maximum(np.abs(b[fin]), 1.0) if scale is None else scale
+    assert np.all(np.abs(a[fin] - b[fin]) <= LOGP_RTOL * s), np.max(np.abs(a[fin] - b[fin]) / s)
+
+
+def _dist(kind, p0, p1, p2, c0):
+    d = A.Dist()
+    d.kind, d.dim = kind, len(p0)
+    for i in range(len(p0)):
+        d.p0[i], d.p1[i], d.p2[i] = float(p0[i]), float(p1[i]), float(p2[i])
+    d.c0 = float(c0)
+    return d
+
+
+@pytest.fixture(scope="module")
+def prim():
+    return load_golden("primitives")
+
+
+@pytest.mark.parametrize("tag", ["std", "lp", "gen", "d1", "d4", "d7", "d8"])
+def test_diag_gaussian(oracle, prim, tag):
+    loc, ls, sc = prim["dg_%s_loc" % tag], prim["dg_%s_log_scale" % tag], prim["dg_%s_scale" % tag]
+    d = len(loc)
+    dist = _dist(A.DIST_DIAG_GAUSS, loc, ls, sc, np.float32(-0.5 * d * np.log(2 * np.pi)))
+    z = prim["dg_%s_z" % tag]
+    out = np.empty(len(z), np.float32)
+    assert oracle.oracle_dist_log_prob(C.byref(dist), z.ctypes.data, len(z), out.ctypes.data) == 0
+    # no transcendental inside log_prob: every op is IEEE + - * /, so this is bit-exact
+    assert np.array_equal(bits(out), bits(prim["dg_%s_log_prob" % tag]))
+    eps = prim["dg_%s_eps" % tag]
+    zz = np.empty_like(eps)
+    lp = np.empty(len(eps), np.float32)
+    assert oracle.oracle_dist_forward(C.byref(dist), eps.ctypes.data, len(eps), zz.ctypes.data, lp.ctypes.data) == 0
+    assert np.array_equal(bits(zz), bits(prim["dg_%s_fwd_z" % tag]))
+    assert np.array_equal(bits(lp), bits(prim["dg_%s_fwd_log_p" % tag]))
+
+
+@pytest.mark.parametrize("tag", ["box", "inc", "d4"])
+def test_uniform(oracle, prim, tag):
+    low, high = prim["un_%s_low" % tag], prim["un_%s_high" % tag]
+    dist = _dist(A.DIST_UNIFORM, low, high, high - low, prim["un_%s_log_prob_val" % tag])
+    z = prim["un_%s_z" % tag]
+    out = np.empty(len(z), np.float32)
+    assert oracle.oracle_dist_log_prob(C.byref(dist), z.ctypes.data, len(z), out.ctypes.data) == 0
+    assert np.array_equal(bits(out), bits(prim["un_%s_log_prob" % tag]))
+    assert np.isfinite(out[0]) and np.isfinite(out[1])          # closed interval (distribution.py:83)
+    u = prim["un_%s_u" % tag]
+    zz = np.empty_like(u)
+    lp = np.empty(len(u), np.float32)
+    assert oracle.oracle_dist_forward(C.byref(dist), u.ctypes.data, len(u), zz.ctypes.data, lp.ctypes.data) == 0
+    assert np.array_equal(bits(zz), bits(prim["un_%s_fwd_z" % tag]))
+    assert np.array_equal(bits(lp), bits(prim["un_%s_fwd_log_p" % tag]))
+
+
+def test_uniform_default_normaliser(prim):
+    # distribution.py:55,71: default bounds have shape (1,), so log_prob_val is -log(4) for any dim
+    assert prim["un_default_log_prob_val"] == np.float32(-np.log(4.0))
+
+
+@pytest.mark.parametrize("eps", [0.05, 0.3])
+def test_mixture_callbacks(oracle, prim, eps):
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    tag = "mix_%g" % eps
+    m = Mixture_set(eps).descriptor()
+    # the descriptor's host-computed constants are the reference's own float32 values
+    assert np.array_equal(bits(np.array(m.noise.p2[:2])), bits(prim[tag + "_noise_scale"]))
+    assert np.array_equal(bits(np.array(m.noise.p1[:2])), bits(prim[tag + "_noise_log_scale"]))
+    assert bits(np.float32(m.kern_scale)) == bits(prim[tag + "_kern_scale"])[0]
+    assert bits(np.float32(m.kern_log_scale)) == bits(prim[tag + "_kern_log_scale"])[0]
+    theta, noise, y = prim[tag + "_theta"], prim[tag + "_noise"], prim[tag + "_y"]
+    n = len(theta)
+    out = np.empty_like(y)
+    assert oracle.oracle_model_simulate(C.byref(m), theta.ctypes.data, noise.ctypes.data, n, out.ctypes.data) == 0
+    assert np.array_equal(bits(out), bits(y))
+    o = np.empty(n, np.float32)
+    assert oracle.oracle_model_prior_log_prob(C.byref(m), theta.ctypes.data, n, o.ctypes.data) == 0
+    assert np.array_equal(bits(o), bits(prim[tag + "_prior"]))
+    # discrepancy ends in a sqrt (IEEE here, ATen's AVX path is 1 ulp off for ~0.7 % of inputs)
+    assert oracle.oracle_model_discrepancy(C.byref(m), y.ctypes.data, n, o.ctypes.data) == 0
+    dis = prim[tag + "_dis"]
+    assert np.all(np.abs(o.astype(np.float64) - dis) <= np.spacing(dis))
+    assert np.mean(bits(o) == bits(dis)) > 0.98
+    assert oracle.oracle_model_log_kernel(C.byref(m), y.ctypes.data, n, o.ctypes.data) == 0
+    _close(o, prim[tag + "_logk"])
+
+
+def test_rowsum_order(oracle, prim):
+    for n in range(1, 18):
+        x = prim["rowsum_%d_x" % n]
+        got = np.array([oracle.oracle_aten_rowsum_f32(r.ctypes.data, n) for r in np.ascontiguousarray(x)], np.float32)
+        assert np.array_equal(bits(got), bits(prim["rowsum_%d_sum" % n])), n
+
+
+def test_esjd(oracle, prim):
+    assert prim["esjd_known"] == np.float32(0.75)
+    i = 0
+    while "esjd_chain_%d" % i in prim:
+        x = prim["esjd_chain_%d" % i]
+        T, d = x.shape
+        hist = np.ascontiguousarray(x.reshape(T, d, 1))
+        out = np.empty(1, np.float32)
+        assert oracle.oracle_esjd(hist.ctypes.data, T, d, 1, 1, out.ctypes.data) == 0
+        ref = prim["esjd_value_%d" % i]
+        assert abs(out[0] - ref) <= 2e-5 * abs(ref), (i, out[0], ref)
+        i += 1
+
+
+def run_oracle(oracle, g, philox_chain0=None):
+    """Run the oracle on a sampler golden's configuration; returns the (T+1, C, d) chains."""
+    cfg = g["cfg"]
+    model, local, glob = descriptors(cfg)
+    C_, T, d = g["theta0"].shape[0], cfg["T"], 2
+    ch = oracle_lib.HostChains(g["theta0"], g["y0"], chain0=cfg.get("chain0", 0))
+    hist = np.zeros((T, d, C_), np.float32)
+    tape = None
+    if str(g["mode"]) == "tape":
+        tape = (np.ascontiguousarray(g["tape_u"]), np.ascontiguousarray(g["tape_r"]),
+                np.ascontiguousarray(g["tape_z"]), g["tape_z"].shape[2])
+    run, keep = oracle_lib.make_run(seed=cfg["seed"], step0=1, n_steps=T, gf=cfg["gf"], batch=cfg["N"],
+                                    history=hist, tape=tape)
+    cs = ch.struct()
+    if str(g["algo"]) == "glmcmc":
+        assert oracle.oracle_init_weights(C.byref(model), C.byref(glob), C.byref(cs)) == 0
+        rc = oracle.oracle_glmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    else:
+        rc = oracle.oracle_globalmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    assert rc == 0
+    chains = np.concatenate([g["theta0"][None], hist.transpose(0, 2, 1)], axis=0)
+    return chains, ch
+
+
+@pytest.mark.parametrize("name", SAMPLER_GOLDENS)
+def test_sampler_chains_bit_exact(oracle, name):
+    """The unmodified reference loop and the oracle, fed the same random numbers, visit the
+    same float32 states at every iteration of every chain."""
+    g = load_golden(name)
+    chains, ch = run_oracle(oracle, g)
+    ref = g["chains"]
+    assert chains.shape == ref.shape
+    same = bits(chains) == bits(ref)
+    assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
+    moves = (np.diff(ref, axis=0) != 0).any(-1).sum(0)
+    assert np.array_equal(ch.n_moves, moves.astype(np.uint32))
+    assert moves.sum() > 0
