@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+Workload (BASELINE.json configs[1]): GLMCMC, iSIR batch N=5, global_frequency 0.9, on
+Mixture_set(eps=0.05), theta_dim 2, 65 536 independent chains per GPU, float32, synthetic
+initial states, Philox random stream; the reference's example proposals
+(examples/Mixture.py:67-69).  One bench "step" = ONE fused kernel launch that advances
+every chain of this GPU by --iters MH iterations, writes every iteration's Theta_Re row
+(the reference records every iteration, GLMCMC.py:89,104) and streams the ESJD / moment
+sums.  value = chain-iterations per second over all GPUs ("MH accept-steps/sec").
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: one process per GPU, chains sharded by global chain id (rank r owns ids
+[r*C, (r+1)*C)), no data-path collective; one RCCL all-gather of the per-chain ESJD /
+moment sums at the end of the timed region (weak scaling: C chains per GPU).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "gl-abc-mcmc_amd"), os.path.join(ROOT, "tests")]
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy rate
+EPS, GF, NBATCH, D = 0.05, 0.9, 5, 2
+
+
+def descriptors():
+    from glabcmcmc_amd import distribution
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    model = Mixture_set(EPS).descriptor()
+    lp = distribution.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35]))).descriptor()
+    ip = distribution.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0])).descriptor()
+    return model, lp, ip
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The CPU checker (oracle/, a plain-C port of the reference loop, OpenMP over chains)
+    timed on this host on a bounded sample of the same workload."""
+    import oracle_lib
+    model, lp, ip = descriptors()
+    cores = min(len(os.sched_getaffinity(0)), 16)            # the GPU box's CPU share for one GPU
+    os.environ["OMP_NUM_THREADS"] = str(cores)                # read by libgomp when the library is first loaded
+    L = oracle_lib.load()
+
+    def run(n, T):
+        hc = oracle_lib.HostChains(np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32))
+        hh = np.zeros((T, 2, n), np.float32)
+        r, keep = oracle_lib.make_run(seed=1, step0=1, n_steps=T, gf=GF, batch=NBATCH, history=hh)
+        cs = hc.struct()
+        L.oracle_init_weights(C.byref(model), C.byref(ip), C.byref(cs))
+        t = time.perf_counter()
+        rc = L.oracle_glmcmc_steps(C.byref(model), C.byref(lp), C.byref(ip), C.byref(cs), C.byref(r))
+        assert rc == 0
+        return n * T / (time.perf_counter() - t)
+
+    for _ in range(3):
+        rate = run(8192, 100)                               # warm (threads, pages, clocks)
+    n = 16384
+    T = int(min(max(50, rate * seconds_target / n), 40000))
+    rate = run(n, T)
+    return {"value": rate, "unit": "chain-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/glabc_oracle.c (C port of GLMCMC.py:58-104), OpenMP over %d threads, %d chains x %d "
+                      "iterations of the bench workload" % (cores, n, T)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--iters", type=int, default=2000, help="MH iterations fused into one launch (= one bench step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-history", action="store_true", help="diagnostic: do not write Theta_Re rows")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default; geometry only)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from glabcmcmc_amd import engine
+    from glabcmcmc_amd.parallel import gather_chain_stats
+    model, lp, ip = descriptors()
+    n, K = args.chains, args.iters
+    seed = 20261003
+
+    # synthetic inputs, resident in HBM before the timed region: theta0 = 0 for every chain,
+    # y0 = |theta0| + sqrt(0.05) z  
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    theta0 = torch.zeros(n, D)
+    y0 = (0.05 ** 0.5) * torch.randn(n, D, generator=g)
+    chains = engine.ChainBatch(theta0, y0, dev, chain0=rank * n)
+    engine.init_weights(model, ip, chains)
+    hist = None if args.no_history else torch.empty(K, D, n, dtype=torch.float32, device=dev)
+    mom = engine.Moments(n, D, dev)
+
+    step_idx = [0]
+
+    def one_step():
+        engine.run_steps("glabc_glmcmc_steps", model, lp, ip, chains, K, 1 + step_idx[0] * K, seed, GF, NBATCH,
+                         history=hist, moments=mom, steps_per_launch=K, lanes_per_chain=args.lanes)
+        step_idx[0] += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()              # torch's current stream = the stream run_steps launches on
+        one_step()
+        b.record()
+    stats = gather_chain_stats(mom, world)          # RCCL all-gather of the per-chain sums (no-op at N=1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    total_steps = float(world) * n * K * args.steps
+    value = total_steps / elapsed
+
+    if rank == 0:
+        # algorithmic HBM bytes of one launch: state in + out, history rows, moment sums in + out
+        S = D + D + 1 + 2                                  # theta, y, log_w, flags, n_moves  (4-byte words)
+        tri = D * (D + 1) // 2
+        state_bytes = 2 * 4 * S * n + 2 * 8 * (D + 2 * tri) * n
+        hist_bytes = 0 if args.no_history else 4 * D * n * K
+        algo_bytes = state_bytes + hist_bytes
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        steps_all = mom.steps
+        esjd_all = stats["esjd"]
+        ok = torch.isfinite(esjd_all)
+        out = {
+            "metric": "MH accept-steps/sec (whole node), 65 536 chains, Mixture_set dim=2",
+            "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GLMCMC iSIR N=5 gf=0.9, Mixture_set eps=0.05 d=2 (BASELINE configs[1])",
+                       "chains_per_gpu": n, "iters_per_step": K, "batch_size": NBATCH, "history": not args.no_history,
+                       "lanes_per_chain": args.lanes or "auto",
+                       "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
+            "esjd_mean": float(esjd_all[ok].double().mean()), "esjd_nan_frac": float(1.0 - ok.double().mean()),
+            "mean_theta": stats["mean"], "mean_theta_sq": stats["mean_sq"],
+            "analytic": {"mean_theta": 0.0, "mean_theta_sq": 2.081014},
+            "moment_iters": steps_all,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "glabc::sampler_kernel<GLMCMC, D=2, N=5>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "bytes_per_chain_step": algo_bytes / (n * K),
+                         "note": "VALU-bound by construction (Philox + Box-Muller + exp per proposal); see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,16 +1,30 @@
 // glabc_device.h -- per-chain device code of the fused GL-ABC-MCMC step (gfx950).
 //
-// One work-item owns one chain for the whole launch: state (theta, y, cached iSIR
-// log-weight, flags, streaming moments) is loaded once into VGPRs, K iterations run
-// back to back in registers, and only the Theta_Re history row (coalesced,
-// chain-major) leaves the CU per iteration.  Every quantity that is the same for all
-// chains (model / proposal parameters, seed, global_frequency) arrives in the kernel
-// argument block, i.e. in SGPRs.
+// Work decomposition.  A chain is owned by a group of L adjacent lanes (L = 1, 2, 4 or 8,
+// a launch-geometry choice that never changes results).  All L lanes keep the chain's
+// state (theta, y, cached densities, iSIR log-weight, flags) in VGPRs for the whole
+// launch; the N proposals of an iteration are dealt round-robin to the lanes
+// (proposal j -> lane j % L, slot j / L), the step-head draw goes to the last lane, and
+// three small exchanges per iteration (ds_bpermute within the group) put the N weights,
+// the local accept bit and the winning candidate on every lane.  With L = 1 this is the
+// plain one-work-item-per-chain form; L > 1 exists because at 65 536 chains one
+// work-item per chain gives one wave per SIMD, and a lone wave can issue a VALU
+// instruction only every other slot (MI355X_MICROARCH.md, "vector-instruction ISSUE cost").
 //
-// The arithmetic follows the reference line by line (citations = /root/reference
-// paths) in float32 with -ffp-contract=off, using the elementary functions and the
-// Philox stream of include/glabc_numerics.h, so that the CPU checker in oracle/
-// (an independent plain-C restatement) can be compared bit for bit.
+// The local move shares proposal slot 0 with the global move: a wavefront holds chains
+// on both sides of the `u < global_frequency` test at almost every iteration, so the two
+// bodies are merged into one instruction stream with per-lane parameter selects instead
+// of two serialized divergent branches.
+//
+// Everything that is the same for all chains (model / proposal parameters, seed,
+// global_frequency) arrives in the kernel argument block, i.e. in SGPRs.
+//
+// The arithmetic follows the reference line by line (citations = /root/reference paths)
+// in float32 with -ffp-contract=off, using the elementary functions and the Philox stream
+// of include/glabc_numerics.h, so the CPU checker in oracle/ (an independent plain-C
+// restatement) can be compared bit for bit.  Deviations from a literal transcription are
+// limited to ones that cannot change a bit: prior(theta_old), K(y_old) and q(theta_old)
+// are cached instead of recomputed (pure functions of the state), and x / 1.0f is x.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -23,10 +37,21 @@ namespace glabc {
 
 #define GLABC_DEV static __device__ __forceinline__
 
+enum Algo { ALGO_GLMCMC = 0, ALGO_GLOBAL = 1 };
+
+// Kernel variants.  VAR_GENERIC reads the distribution kinds / unit-scale flags from the
+// argument block (wave-uniform branches).  VAR_GAUSS_UNIT is the reference example's class of
+// configuration -- prior, local and global proposals all DiagGaussian, prior and global with
+// exp(log_scale) == 1 (examples/Mixture.py:30,68) -- with those facts known at compile time,
+// which removes every branch from a candidate's evaluation so the scheduler can interleave
+// the independent candidates of a lane.
+enum Variant { VAR_GENERIC = 0, VAR_GAUSS_UNIT = 1 };
+
 // ---- argument block ------------------------------------------------------------
 template <int D>
 struct DistArgs {
     int32_t kind;
+    int32_t unit_scale;          // DiagGaussian with every exp(log_scale) == 1.0f: (z-loc)/1 == z-loc
     float c0;
     float p0[D], p1[D], p2[D];
 };
@@ -114,15 +139,23 @@ GLABC_DEV float aten_rowsum(const float (&x)[N])
 
 // ---- distribution.py ---------------------------------------------------------------
 // DiagGaussian.log_prob, distribution.py:176-181 / Uniform.log_prob, distribution.py:81-86
-template <int D>
+template <int D, bool KNOWN_GAUSS_UNIT = false>
 GLABC_DEV float dist_log_prob(const DistArgs<D>& g, const float (&z)[D])
 {
-    if (g.kind == GLABC_DIST_DIAG_GAUSS) {
+    if (KNOWN_GAUSS_UNIT || g.kind == GLABC_DIST_DIAG_GAUSS) {
         float t[D];
+        if (KNOWN_GAUSS_UNIT || g.unit_scale) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            float e = (z[j] - g.p0[j]) / g.p2[j];
-            t[j] = g.p1[j] + 0.5f * (e * e);
+            for (int j = 0; j < D; ++j) {
+                float e = z[j] - g.p0[j];                    // == (z - loc) / 1.0f, bit for bit
+                t[j] = g.p1[j] + 0.5f * (e * e);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float e = (z[j] - g.p0[j]) / g.p2[j];
+                t[j] = g.p1[j] + 0.5f * (e * e);
+            }
         }
         return g.c0 - aten_rowsum<D>(t);
     } else {
@@ -133,14 +166,11 @@ GLABC_DEV float dist_log_prob(const DistArgs<D>& g, const float (&z)[D])
     }
 }
 
-// forward() given its noise: DiagGaussian distribution.py:166-174 (noise = N(0,1) draws),
-// Uniform distribution.py:73-79 (noise = [0,1) draws)
-template <int D>
-GLABC_DEV float dist_forward(const DistArgs<D>& g, const float (&noise)[D], float (&z)[D])
+// log_p of forward() given its noise: DiagGaussian distribution.py:171-173, Uniform :78
+template <int D, bool KNOWN_GAUSS = false>
+GLABC_DEV float dist_forward_log_p(const DistArgs<D>& g, const float (&noise)[D])
 {
-#pragma unroll
-    for (int j = 0; j < D; ++j) z[j] = g.p0[j] + g.p2[j] * noise[j];
-    if (g.kind == GLABC_DIST_DIAG_GAUSS) {
+    if (KNOWN_GAUSS || g.kind == GLABC_DIST_DIAG_GAUSS) {
         float t[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) t[j] = g.p1[j] + 0.5f * (noise[j] * noise[j]);
@@ -177,47 +207,61 @@ GLABC_DEV float model_log_kernel(const StepArgs<D>& a, const float (&y)[D])
 }
 
 // ---- random draws of one (chain, step) ---------------------------------------------
-struct StepHead {
-    float u_branch, u_accept;
-    double u_resample;
-};
-
 struct Rng {
     uint32_t c0, c1, k0, k1;
 };
 
-GLABC_DEV StepHead draw_head(const Rng& r, uint32_t step)
+// ---- lane-group exchange -----------------------------------------------------------------
+// Groups are 1, 2 or 4 adjacent lanes, i.e. they sit inside one DPP quad: a value held by
+// group lane SRC (compile-time) reaches every lane of the group with one v_mov_b32_dpp
+// quad_perm (a VALU op; a ds_bpermute costs ~10x the SIMD time -- tools/ubench).  A run-time
+// source lane (the owner of the winning candidate, needed only when some chain of the
+// wavefront moves) goes through ds_bpermute.  Every lane of the wave must execute these.
+template <int L, int SRC>
+GLABC_DEV int group_bcast_i(int v)
 {
-    glabc_u32x4 h = glabc_philox4x32_10(r.c0, r.c1, step, 0u, r.k0, r.k1);
-    StepHead s;
-    s.u_branch = glabc_uniform_f32(h.v[0]);
-    s.u_accept = glabc_uniform_f32(h.v[1]);
-    s.u_resample = glabc_uniform_f64(h.v[2], h.v[3]);
-    return s;
+    if constexpr (L == 1) {
+        return v;
+    } else if constexpr (L == 2) {
+        constexpr int ctrl = SRC | (SRC << 2) | ((2 + SRC) << 4) | ((2 + SRC) << 6);     // quad_perm:[s,s,2+s,2+s]
+        return __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true);
+    } else {
+        static_assert(L == 4, "lane groups are 1, 2 or 4 wide");
+        constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);                 // quad_perm:[s,s,s,s]
+        return __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true);
+    }
 }
 
-// Proposal j of a step: D proposal draws then D simulator draws out of
-// ceil(2D/4) Philox blocks at slots 1 + j*spp + b.  Normals come in Box-Muller
-// pairs from words (2i, 2i+1); a Uniform proposal takes word i as a [0,1) uniform.
-template <int D>
-GLABC_DEV void draw_proposal(const Rng& r, uint32_t step, int j, bool uniform_prop, float (&e)[D], float (&s)[D])
+template <int L, int SRC>
+GLABC_DEV float group_bcast(float v)
 {
-    constexpr int M = 2 * D;
-    constexpr int SPP = (M + 3) / 4;
-    uint32_t w[4 * SPP];
-#pragma unroll
-    for (int b = 0; b < SPP; ++b) {
-        glabc_u32x4 o = glabc_philox4x32_10(r.c0, r.c1, step, (uint32_t)(1 + j * SPP + b), r.k0, r.k1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[4 * b + q] = o.v[q];
+    return __builtin_bit_cast(float, group_bcast_i<L, SRC>(__builtin_bit_cast(int, v)));
+}
+
+template <int L>
+GLABC_DEV float group_get_dyn(float v, int src)
+{
+    if constexpr (L == 1) {
+        return v;
+    } else {
+        const int lane = (int)(threadIdx.x & 63u);
+        return __shfl(v, (lane & ~(L - 1)) | src, 64);
     }
-    float nrm[2 * ((M + 1) / 2)];
-#pragma unroll
-    for (int i = 0; 2 * i < M; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        e[i] = uniform_prop ? glabc_uniform_f32(w[i]) : nrm[i];
-        s[i] = nrm[D + i];
+}
+
+// weight of candidate K-1 (K = 1..N, compile-time) from its owner lane (K-1) % L, slot (K-1) / L
+template <int L, int K, int NL>
+GLABC_DEV float gather_weight(const float (&wl)[NL])
+{
+    return group_bcast<L, (K - 1) % L>(wl[(K - 1) / L]);
+}
+
+template <int L, int N, int NL, int K = 1>
+GLABC_DEV void gather_weights(const float (&wl)[NL], float (&w)[N + 1])
+{
+    if constexpr (K <= N) {
+        w[K] = gather_weight<L, K, NL>(wl);
+        gather_weights<L, N, NL, K + 1>(wl, w);
     }
 }
 
@@ -226,111 +270,213 @@ template <int D>
 struct Chain {
     float theta[D];
     float y[D];
-    float log_w;
+    float prior;      // prior_log_prob(theta)         (cache of a pure function of the state)
+    float kern;       // calculate_log_kernel(y)       (cache)
+    float q;          // global/importance log_prob(theta)  (cache)
+    float log_w;      // log_weight_old, GLMCMC.py:53-55
     uint32_t flags;
     uint32_t n_moves;
 };
 
-// random-walk MH local move, GLMCMC.py:90-104 == GlobalMCMC.py:55-68
-//   theta' = Local_Proposal.sample(1) + theta ; log_acc = ((prior' + K') - prior) - K
 template <int D>
-GLABC_DEV bool local_move(const StepArgs<D>& a, const Rng& r, uint32_t step, float u_accept, Chain<D>& c)
+GLABC_DEV void refresh_cache(const StepArgs<D>& a, Chain<D>& c)
 {
-    float e[D], s[D], inc[D], th[D], y[D];
-    draw_proposal<D>(r, step, 0, a.local.kind == GLABC_DIST_UNIFORM, e, s);
-    (void)dist_forward<D>(a.local, e, inc);
+    c.prior = dist_log_prob<D>(a.prior, c.theta);
+    c.kern = model_log_kernel<D>(a, c.y);
+    c.q = dist_log_prob<D>(a.global, c.theta);
+}
+
+// One iteration of GLMCMC (GLMCMC.py:58-104) or GlobalMCMC (GlobalMCMC.py:37-68) for the
+// chain owned by this lane group; `sub` is this lane's index in the group.
+//
+// Candidate j of the iteration (j = 0..N-1) is evaluated by lane j % L in its slot j / L:
+//   global move : theta' = loc + scale*eps               GLMCMC.py:66 / GlobalMCMC.py:40
+//   local move  : theta' = (loc + scale*eps) + theta     GLMCMC.py:91 / GlobalMCMC.py:56  (candidate 0 only)
+//   y' = simulate(theta')                                GLMCMC.py:71,94
+//   prior', K'                                           GLMCMC.py:72-74,96
+// then
+//   iSIR        : w = exp(cat(lw_old, (prior'+K') - q')), NaN -> 0, w /= sum(w), inverse-CDF index in
+//                 double against a double uniform         GLMCMC.py:75-84, 7-22
+//   MH          : log(u) < ((prior'+K') - prior) - K                       GLMCMC.py:96-99
+//                 log(u) < ((((prior'+K') + q) - q') - prior) - K          GlobalMCMC.py:44-47
+template <int ALGO, int D, int N, int L, int VAR>
+GLABC_DEV bool chain_step(const StepArgs<D>& a, const Rng& rng, uint32_t step, int sub, Chain<D>& c)
+{
+    constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
+    constexpr int NL = (N + L - 1) / L;            // candidate slots per lane
+    constexpr int HEAD = L - 1;                    // the lane with the fewest candidates draws the step head
+    // When N is not a multiple of L the last slot of lane L-1 holds no candidate: the step head
+    // (Philox slot 0) is drawn there, in the same instruction stream as the other lanes'
+    // candidates of that pass, and that pass runs first so candidate 0 knows its branch.
+    constexpr bool FREE_SLOT = (L > 1) && (N % L != 0) && (NL >= 2);
+    constexpr int SPP = (2 * D + 3) / 4;
+
+    uint32_t hw[4];
+    float log_u = 0.0f;
+    bool is_global = false;
+    auto take_head = [&]() {
+        if constexpr (L > 1) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) th[j] = inc[j] + c.theta[j];
-    model_simulate<D>(a, th, s, y);
-    float log_acc = ((dist_log_prob<D>(a.prior, th) + model_log_kernel<D>(a, y)) - dist_log_prob<D>(a.prior, c.theta)) -
-                    model_log_kernel<D>(a, c.y);
-    bool acc = glabc_logf(u_accept) < log_acc;
-    if (acc) {
+            for (int q = 0; q < 4; ++q) hw[q] = (uint32_t)group_bcast_i<L, HEAD>((int)hw[q]);
+        }
+        log_u = glabc_logf(glabc_uniform_f32(hw[1]));                           // GLMCMC.py:98 (u = 0 -> -inf)
+        is_global = glabc_uniform_f32(hw[0]) < a.gf;                          // GLMCMC.py:59 / GlobalMCMC.py:39
+        if (ALGO == ALGO_GLMCMC && is_global) {
+            if (c.flags & GLABC_FLAG_LOCAL) c.log_w = (c.prior + c.kern) - c.q;   // GLMCMC.py:60-64
+            c.flags &= ~GLABC_FLAG_LOCAL;                                         // GLMCMC.py:65
+        }
+    };
+    if constexpr (!FREE_SLOT) {
+        if (L == 1 || sub == HEAD) {
+            glabc_u32x4 h = glabc_philox4x32_10(rng.c0, rng.c1, step, 0u, rng.k0, rng.k1);
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            c.theta[j] = th[j];
-            c.y[j] = y[j];
+            for (int q = 0; q < 4; ++q) hw[q] = h.v[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hw[q] = 0u;
+        }
+        take_head();
+    }
+
+    // ---- this lane's candidates ----
+    float th[NL][D], yy[NL][D], lw[NL], pr[NL], kk[NL], wl[NL];
+    bool acc_mh = false;
+    const bool g_uni = !GU && a.global.kind == GLABC_DIST_UNIFORM;
+    const bool l_uni = !GU && a.local.kind == GLABC_DIST_UNIFORM;
+#pragma unroll
+    for (int rr = 0; rr < NL; ++rr) {
+        const int r = FREE_SLOT ? (NL - 1 - rr) : rr;
+        const int j = sub + L * r;                  // candidate index of this slot (>= N: unused slot)
+        const bool head_pass = FREE_SLOT && (r == NL - 1);
+        const bool first = (r == 0) && (L == 1 || sub == 0);                  // candidate 0 doubles as the local move
+        // Philox blocks of this slot: D proposal draws then D simulator draws out of ceil(2D/4)
+        // blocks at slots 1 + j*SPP + b; normals in Box-Muller pairs from words (2i, 2i+1)
+        uint32_t w[4 * SPP];
+#pragma unroll
+        for (int b = 0; b < SPP; ++b) {
+            uint32_t slot_id = (uint32_t)(1 + j * SPP + b);
+            if (head_pass && b == 0) slot_id = (sub == HEAD) ? 0u : slot_id;
+            glabc_u32x4 o = glabc_philox4x32_10(rng.c0, rng.c1, step, slot_id, rng.k0, rng.k1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[4 * b + q] = o.v[q];
+        }
+        if (head_pass) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hw[q] = w[q];
+            take_head();
+        }
+        const bool loc = first && !is_global;
+        const bool uni = loc ? l_uni : g_uni;
+        float nrm[2 * D], e[D], s[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            e[i] = (!GU && uni) ? glabc_uniform_f32(w[i]) : nrm[i];
+            s[i] = nrm[D + i];
+        }
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+            const float p0 = loc ? a.local.p0[q] : a.global.p0[q];
+            const float p2 = loc ? a.local.p2[q] : a.global.p2[q];
+            const float t = p0 + p2 * e[q];                                   // distribution.py:170 / :77
+            th[r][q] = loc ? (t + c.theta[q]) : t;                            // GLMCMC.py:91
+        }
+        const float lq = dist_forward_log_p<D, GU>(a.global, e);              // unused by the local move
+        model_simulate<D>(a, th[r], s, yy[r]);
+        pr[r] = dist_log_prob<D, GU>(a.prior, th[r]);
+        kk[r] = model_log_kernel<D>(a, yy[r]);
+        const float pk = pr[r] + kk[r];
+        lw[r] = pk - lq;                                                      // GLMCMC.py:74
+        if (r == 0) {
+            float log_acc;
+            if (ALGO == ALGO_GLOBAL)
+                log_acc = loc ? ((pk - c.prior) - c.kern)                     // GlobalMCMC.py:60-61
+                              : ((((pk + c.q) - lq) - c.prior) - c.kern);     // GlobalMCMC.py:44-46
+            else
+                log_acc = (pk - c.prior) - c.kern;                            // GLMCMC.py:96-97
+            acc_mh = log_u < log_acc;                                         // GLMCMC.py:98-99
+        }
+        if (ALGO == ALGO_GLMCMC) {
+            const float v = glabc_expf(lw[r]);                                // GLMCMC.py:78
+            wl[r] = (v != v) ? 0.0f : v;                                      // GLMCMC.py:80-81
         }
     }
-    return acc;
-}
 
-// independence MH global move, GlobalMCMC.py:39-53
-//   log_acc = ((((prior' + K') + q(theta)) - q') - prior) - K
-template <int D>
-GLABC_DEV bool independence_move(const StepArgs<D>& a, const Rng& r, uint32_t step, float u_accept, Chain<D>& c)
-{
-    float e[D], s[D], th[D], y[D];
-    draw_proposal<D>(r, step, 0, a.global.kind == GLABC_DIST_UNIFORM, e, s);
-    float lq_new = dist_forward<D>(a.global, e, th);
-    model_simulate<D>(a, th, s, y);
-    float lq_old = dist_log_prob<D>(a.global, c.theta);
-    float log_acc = ((((dist_log_prob<D>(a.prior, th) + model_log_kernel<D>(a, y)) + lq_old) - lq_new) -
-                     dist_log_prob<D>(a.prior, c.theta)) -
-                    model_log_kernel<D>(a, c.y);
-    bool acc = glabc_logf(u_accept) < log_acc;
-    if (acc) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            c.theta[j] = th[j];
-            c.y[j] = y[j];
+    // ---- winner index: 0 = stay, k = candidate k-1 ----
+    int ind;
+    if constexpr (ALGO == ALGO_GLMCMC) {
+        float w[N + 1];
+        {
+            const float v = glabc_expf(c.log_w);
+            w[0] = (v != v) ? 0.0f : v;
         }
+        gather_weights<L, N, NL>(wl, w);
+        const float tot = aten_rowsum<N + 1>(w);                              // GLMCMC.py:82
+        const double u_res = glabc_uniform_f64(hw[2], hw[3]);
+        int ig = -1;
+        double run = 0.0;
+#pragma unroll
+        for (int k = 0; k <= N; ++k) {
+            run += (double)(w[k] / tot);
+            ig = (ig < 0 && u_res < run) ? k : ig;                            // weight_sampling, GLMCMC.py:17-22
+        }
+        ig = ig < 0 ? 0 : ig;                                                 // None -> stay, GLMCMC.py:84
+        const int il = group_bcast_i<L, 0>(acc_mh ? 1 : 0);
+        ind = is_global ? ig : il;
+    } else {
+        ind = group_bcast_i<L, 0>(acc_mh ? 1 : 0);
     }
-    return acc;
-}
 
-// log_weight_old, GLMCMC.py:53-55 / 62-64
-template <int D>
-GLABC_DEV float isir_weight_of_state(const StepArgs<D>& a, const Chain<D>& c)
-{
-    return (dist_log_prob<D>(a.prior, c.theta) + model_log_kernel<D>(a, c.y)) - dist_log_prob<D>(a.global, c.theta);
-}
-
-// iSIR global move, GLMCMC.py:60-88.  The N proposals, their simulations and the N+1
-// weights live in registers (N is a template parameter); the resampling index is the
-// reference's double-precision running sum against a double uniform (GLMCMC.py:7-22).
-// (The NaN-row filter of GLMCMC.py:67-70 cannot trigger: the entry point rejects
-// non-finite proposal parameters and the draws are finite.)
-template <int D, int N>
-GLABC_DEV bool isir_move(const StepArgs<D>& a, const Rng& r, uint32_t step, double u_resample, Chain<D>& c)
-{
-    float th[N][D], y[N][D];
-    float lw[N + 1], w[N + 1];
-    if (c.flags & GLABC_FLAG_LOCAL) c.log_w = isir_weight_of_state<D>(a, c);   // :60-64
-    c.flags &= ~GLABC_FLAG_LOCAL;                                              // :65
-    lw[0] = c.log_w;
-    const bool uni = a.global.kind == GLABC_DIST_UNIFORM;
+    // ---- move: fetch the winning candidate from its owner lane ----
+    const bool moved = ind > 0;
+    if (__any(moved)) {
+        const int owner = (ind - 1) & (L - 1);
+        const int slot = (ind - 1) / L;
+        // this lane's candidate in the winning slot (conditional moves over the unrolled slots keep
+        // everything in VGPRs; a run-time array index would be promoted to LDS / scratch)
+        float nt[D], ny[D], nlw = lw[0], npr = pr[0], nkk = kk[0];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        float e[D], s[D];
-        draw_proposal<D>(r, step, j, uni, e, s);
-        float lq = dist_forward<D>(a.global, e, th[j]);                       // :66
-        model_simulate<D>(a, th[j], s, y[j]);                                  // :71
-        lw[j + 1] = (dist_log_prob<D>(a.prior, th[j]) + model_log_kernel<D>(a, y[j])) - lq;   // :72-74
-    }
+        for (int q = 0; q < D; ++q) {
+            nt[q] = th[0][q];
+            ny[q] = yy[0][q];
+        }
 #pragma unroll
-    for (int k = 0; k <= N; ++k) {
-        float v = glabc_expf(lw[k]);                                           // :78
-        w[k] = (v != v) ? 0.0f : v;                                            // :80-81
-    }
-    float tot = aten_rowsum<N + 1>(w);                                         // :82
-    int ind = -1;
-    double run = 0.0;
+        for (int r = 1; r < NL; ++r) {
+            if (slot == r) {
 #pragma unroll
-    for (int k = 0; k <= N; ++k) {
-        run += (double)(w[k] / tot);
-        ind = (ind < 0 && u_resample < run) ? k : ind;                         // weight_sampling :17-22
-    }
-    bool moved = ind > 0;                                                      // :84
+                for (int q = 0; q < D; ++q) {
+                    nt[q] = th[r][q];
+                    ny[q] = yy[r][q];
+                }
+                nlw = lw[r];
+                npr = pr[r];
+                nkk = kk[r];
+            }
+        }
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        if (ind == j + 1) {
+        for (int q = 0; q < D; ++q) {
+            nt[q] = group_get_dyn<L>(nt[q], owner);
+            ny[q] = group_get_dyn<L>(ny[q], owner);
+        }
+        nlw = group_get_dyn<L>(nlw, owner);
+        npr = group_get_dyn<L>(npr, owner);
+        nkk = group_get_dyn<L>(nkk, owner);
+        if (moved) {
 #pragma unroll
             for (int q = 0; q < D; ++q) {
-                c.theta[q] = th[j][q];
-                c.y[q] = y[j][q];
+                c.theta[q] = nt[q];
+                c.y[q] = ny[q];
             }
-            c.log_w = lw[j + 1];
+            c.prior = npr;
+            c.kern = nkk;
+            c.q = dist_log_prob<D, GU>(a.global, c.theta);
+            if (ALGO == ALGO_GLMCMC) {
+                if (is_global)
+                    c.log_w = nlw;                                            // GLMCMC.py:86
+                else
+                    c.flags |= GLABC_FLAG_LOCAL;                              // GLMCMC.py:100
+            }
         }
     }
     return moved;

@@ -1,10 +1,11 @@
 // glabc_hip.hip -- gfx950 kernels and the C ABI of include/glabc.h.
 //
-// Build (see __graft_entry__.build):
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared glabc_hip.hip -o libglabc_hip.so
+// Build: csrc/Makefile (driven by __graft_entry__.build):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -c   (this file + glabc_sampler_dim.hip x 4 dims)
+//   hipcc -shared *.o -o libglabc_hip.so
 //
 // Kernels
-//   sampler_kernel<ALGO, D, N>   fused K-iteration GLMCMC / GlobalMCMC step, one work-item per chain
+//   sampler_kernel<ALGO, D, N, L> fused K-iteration GLMCMC / GlobalMCMC step (glabc_sampler.h, one TU per D)
 //   init_weights_kernel<D>       GLMCMC.py:52-55
 //   rowwise_kernel<OP>           distribution / Model callbacks on row-major points
 //   esjd_kernel<D>               ESJD.py:2-25 per chain from a chain-major history
@@ -14,112 +15,9 @@
 #include <cstdint>
 #include <cstring>
 
-#include "glabc_device.h"
+#include "glabc_sampler.h"
 
 namespace glabc {
-
-enum Algo { ALGO_GLMCMC = 0, ALGO_GLOBAL = 1 };
-
-constexpr int BLOCK = 64;      // one wavefront per workgroup: 65 536 chains -> 1024 workgroups over 256 CUs x 4 SIMDs
-
-// ---- the fused sampler ------------------------------------------------------------------
-template <int ALGO, int D, int N>
-__global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D> a)
-{
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.n_chains) return;
-
-    Chain<D> c;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        c.theta[j] = a.theta[j * a.stride + i];
-        c.y[j] = a.y[j * a.stride + i];
-    }
-    c.log_w = (ALGO == ALGO_GLMCMC) ? a.log_w[i] : 0.0f;
-    c.flags = (ALGO == ALGO_GLMCMC) ? a.flags[i] : 0u;
-    c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
-
-    constexpr int TRI = D * (D + 1) / 2;
-    const bool mom = a.sum_theta != nullptr;
-    double s1[D], s2[TRI], sj[TRI];
-    if (mom) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) s1[j] = a.sum_theta[j * a.stride + i];
-#pragma unroll
-        for (int k = 0; k < TRI; ++k) {
-            s2[k] = a.sum_outer[k * a.stride + i];
-            sj[k] = a.sum_jump[k * a.stride + i];
-        }
-    }
-
-    const uint64_t gid = (uint64_t)(a.chain0 + i);
-    Rng rng;
-    rng.c0 = (uint32_t)gid;
-    rng.c1 = (uint32_t)(gid >> 32);
-    rng.k0 = a.seed_lo;
-    rng.k1 = a.seed_hi;
-
-    float* hist = a.history ? a.history + i : nullptr;
-
-    for (int t = 0; t < a.n_steps; ++t) {
-        const uint32_t step = a.step0 + (uint32_t)t;
-        float prev[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) prev[j] = c.theta[j];
-
-        StepHead h = draw_head(rng, step);
-        bool moved;
-        if (h.u_branch < a.gf) {                                   // GLMCMC.py:59 / GlobalMCMC.py:39
-            if constexpr (ALGO == ALGO_GLMCMC)
-                moved = isir_move<D, N>(a, rng, step, h.u_resample, c);
-            else
-                moved = independence_move<D>(a, rng, step, h.u_accept, c);
-        } else {
-            moved = local_move<D>(a, rng, step, h.u_accept, c);
-            if (ALGO == ALGO_GLMCMC && moved) c.flags |= GLABC_FLAG_LOCAL;    // GLMCMC.py:100
-        }
-        c.n_moves += moved ? 1u : 0u;
-
-        if (hist) {                                                // Theta_Re[i,:] = Theta_old, GLMCMC.py:89,104
-#pragma unroll
-            for (int j = 0; j < D; ++j) hist[((int64_t)t * D + j) * a.hist_stride] = c.theta[j];
-        }
-        if (mom) {
-            int k = 0;
-#pragma unroll
-            for (int p = 0; p < D; ++p) {
-                s1[p] += (double)c.theta[p];
-#pragma unroll
-                for (int q = p; q < D; ++q, ++k) {
-                    s2[k] += (double)c.theta[p] * (double)c.theta[q];
-                    double dp = (double)c.theta[p] - (double)prev[p];
-                    double dq = (double)c.theta[q] - (double)prev[q];
-                    sj[k] += dp * dq;
-                }
-            }
-        }
-    }
-
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        a.theta[j * a.stride + i] = c.theta[j];
-        a.y[j * a.stride + i] = c.y[j];
-    }
-    if (ALGO == ALGO_GLMCMC) {
-        a.log_w[i] = c.log_w;
-        a.flags[i] = c.flags;
-    }
-    if (a.n_moves) a.n_moves[i] = c.n_moves;
-    if (mom) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) a.sum_theta[j * a.stride + i] = s1[j];
-#pragma unroll
-        for (int k = 0; k < TRI; ++k) {
-            a.sum_outer[k * a.stride + i] = s2[k];
-            a.sum_jump[k * a.stride + i] = sj[k];
-        }
-    }
-}
 
 template <int D>
 __global__ void __launch_bounds__(BLOCK) init_weights_kernel(const StepArgs<D> a)
@@ -132,7 +30,8 @@ __global__ void __launch_bounds__(BLOCK) init_weights_kernel(const StepArgs<D> a
         c.theta[j] = a.theta[j * a.stride + i];
         c.y[j] = a.y[j * a.stride + i];
     }
-    a.log_w[i] = isir_weight_of_state<D>(a, c);
+    refresh_cache<D>(a, c);
+    a.log_w[i] = (c.prior + c.kern) - c.q;                         // GLMCMC.py:52-55
     a.flags[i] = a.flags[i] | GLABC_FLAG_LOCAL;                    // GLMCMC.py:50
 }
 
@@ -155,12 +54,15 @@ __device__ __forceinline__ DistArgs<D> narrow(const glabc_dist& g)
     DistArgs<D> o;
     o.kind = g.kind;
     o.c0 = g.c0;
+    bool unit = g.kind == GLABC_DIST_DIAG_GAUSS;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         o.p0[j] = g.p0[j];
         o.p1[j] = g.p1[j];
         o.p2[j] = g.p2[j];
+        unit = unit && (g.p2[j] == 1.0f);
     }
+    o.unit_scale = unit ? 1 : 0;
     return o;
 }
 
@@ -284,6 +186,41 @@ __global__ void __launch_bounds__(BLOCK) moments_esjd_kernel(const double* __res
     out[c] = det_root<D>(m, (float)n_steps);
 }
 
+
+// ---- numerics self-test hooks (device evaluation of include/glabc_numerics.h) -------------------
+// op 0: expf  1: logf  2: sin(2 pi u)  3: cos(2 pi u)  4: normal_pair(a,b).z0  5: .z1 (in = 2 u32 words per item)
+__global__ void __launch_bounds__(256) numerics_kernel(int op, const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    if (op == 0) r = glabc_expf(glabc_u2f(in[i]));
+    else if (op == 1) r = glabc_logf(glabc_u2f(in[i]));
+    else if (op == 2 || op == 3) {
+        float sn, cs;
+        glabc_sincos2pi(glabc_u2f(in[i]), &sn, &cs);
+        r = op == 2 ? sn : cs;
+    } else {
+        float z0, z1;
+        glabc_normal_pair(in[2 * i], in[2 * i + 1], &z0, &z1);
+        r = op == 4 ? z0 : z1;
+    }
+    out[i] = glabc_f2u(r);
+}
+
+// glabc_sqrtf_normal against the exactly rounded (float)sqrt((double)x) for every float with bit
+// pattern in [first, last]; counts mismatches (both are expected to be IEEE-correct on 0 and normals)
+__global__ void __launch_bounds__(256) sqrt_check_kernel(uint32_t first, uint32_t last, unsigned long long* __restrict__ bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    unsigned long long local = 0;
+    for (uint64_t b = (uint64_t)first + (uint64_t)blockIdx.x * 256 + threadIdx.x; b <= (uint64_t)last; b += stride) {
+        const float x = glabc_u2f((uint32_t)b);
+        const float want = (float)__builtin_sqrt((double)x);
+        local += (glabc_f2u(glabc_sqrtf_normal(x)) != glabc_f2u(want)) ? 1ull : 0ull;
+    }
+    if (local) atomicAdd(bad, local);
+}
 }  // namespace glabc
 
 // =================================================================================================
@@ -336,11 +273,14 @@ static DistArgs<D> pack_dist(const glabc_dist* g)
     DistArgs<D> o;
     o.kind = g->kind;
     o.c0 = g->c0;
+    bool unit = g->kind == GLABC_DIST_DIAG_GAUSS;
     for (int j = 0; j < D; ++j) {
         o.p0[j] = g->p0[j];
         o.p1[j] = g->p1[j];
         o.p2[j] = g->p2[j];
+        unit = unit && (g->p2[j] == 1.0f);
     }
+    o.unit_scale = unit ? 1 : 0;
     return o;
 }
 
@@ -398,29 +338,6 @@ static int finish_launch()
 
 static unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
-template <int ALGO, int D, int N>
-static int launch_sampler(const StepArgs<D>& a, hipStream_t s)
-{
-    hipLaunchKernelGGL((sampler_kernel<ALGO, D, N>), dim3(grid_for(a.n_chains, BLOCK)), dim3(BLOCK), 0, s, a);
-    return finish_launch();
-}
-
-template <int ALGO, int D>
-static int dispatch_batch(const StepArgs<D>& a, int N, hipStream_t s)
-{
-    if constexpr (ALGO == ALGO_GLOBAL) {
-        return launch_sampler<ALGO, D, 1>(a, s);
-    } else {
-        switch (N) {
-#define GLABC_CASE(n) case n: return launch_sampler<ALGO, D, n>(a, s);
-            GLABC_CASE(1) GLABC_CASE(2) GLABC_CASE(3) GLABC_CASE(4) GLABC_CASE(5) GLABC_CASE(6) GLABC_CASE(7) GLABC_CASE(8)
-            GLABC_CASE(9) GLABC_CASE(10) GLABC_CASE(11) GLABC_CASE(12) GLABC_CASE(13) GLABC_CASE(14) GLABC_CASE(15) GLABC_CASE(16)
-#undef GLABC_CASE
-        default: return GLABC_ERR_ARG;
-        }
-    }
-}
-
 static int check_run(const glabc_model* m, const glabc_dist* local, const glabc_dist* global, const glabc_chains* c,
                      const glabc_run* r, bool isir)
 {
@@ -437,6 +354,8 @@ static int check_run(const glabc_model* m, const glabc_dist* local, const glabc_
     if (r->n_steps < 0) return GLABC_ERR_ARG;
     if (!(r->global_frequency >= 0.0f) && !(r->global_frequency < 0.0f)) return GLABC_ERR_ARG;    // NaN
     if (isir && (r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH)) return GLABC_ERR_ARG;
+    if (r->lanes_per_chain != 0 && r->lanes_per_chain != 1 && r->lanes_per_chain != 2 && r->lanes_per_chain != 4)
+        return GLABC_ERR_ARG;
     if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
     if (r->moments && (!r->moments->sum_theta || !r->moments->sum_outer || !r->moments->sum_jump)) return GLABC_ERR_NULL;
     if (r->tape) return GLABC_ERR_ARG;       // tape replay is implemented by the CPU checker only (for now)
@@ -444,21 +363,41 @@ static int check_run(const glabc_model* m, const glabc_dist* local, const glabc_
     return GLABC_OK;
 }
 
-template <int ALGO>
-static int run_sampler(const glabc_model* m, const glabc_dist* local, const glabc_dist* global, const glabc_chains* c,
-                       const glabc_run* r, void* stream)
+// lanes per chain: a launch-geometry choice (results do not depend on it).  Measured on MI355X
+// (profiles/): with the branch-free candidate code one wave per SIMD already interleaves its N
+// independent candidates, and one work-item per chain is fastest at 65 536 chains for N = 5
+// (6.3 ms / 2000 iterations vs 6.8 ms with 2 lanes, 9.2 ms with 4); the split only pays when a
+// launch would otherwise leave SIMDs empty (fewer chains than lanes on the chip).
+static int pick_lanes(int requested, int n_batch, int64_t n_chains)
 {
-    int rc = check_run(m, local, global, c, r, ALGO == ALGO_GLMCMC);
+    int lanes = requested;
+    if (lanes <= 0) {
+        const int64_t chip_lanes = 64 * 1024;                // one wave on each of the 1024 SIMDs
+        lanes = 1;
+        while (lanes < 4 && n_chains * lanes < chip_lanes) lanes *= 2;
+    }
+    if (lanes >= 4 && n_batch >= 3) return 4;
+    if (lanes >= 2 && n_batch >= 2) return 2;
+    return 1;
+}
+
+static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, const glabc_dist* global,
+                       const glabc_chains* c, const glabc_run* r, void* stream)
+{
+    int rc = check_run(m, local, global, c, r, algo == ALGO_GLMCMC);
     if (rc) return rc;
     if (c->n_chains == 0 || r->n_steps == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;
+    const int lanes = algo == ALGO_GLMCMC ? pick_lanes(r->lanes_per_chain, r->batch_size, c->n_chains) : 1;
     switch (m->theta_dim) {
-    case 1: return dispatch_batch<ALGO, 1>(pack_args<1>(m, local, global, c, r), r->batch_size, s);
-    case 2: return dispatch_batch<ALGO, 2>(pack_args<2>(m, local, global, c, r), r->batch_size, s);
-    case 3: return dispatch_batch<ALGO, 3>(pack_args<3>(m, local, global, c, r), r->batch_size, s);
-    case 4: return dispatch_batch<ALGO, 4>(pack_args<4>(m, local, global, c, r), r->batch_size, s);
+    case 1: rc = launch_sampler_dim<1>(algo, r->batch_size, lanes, pack_args<1>(m, local, global, c, r), s); break;
+    case 2: rc = launch_sampler_dim<2>(algo, r->batch_size, lanes, pack_args<2>(m, local, global, c, r), s); break;
+    case 3: rc = launch_sampler_dim<3>(algo, r->batch_size, lanes, pack_args<3>(m, local, global, c, r), s); break;
+    case 4: rc = launch_sampler_dim<4>(algo, r->batch_size, lanes, pack_args<4>(m, local, global, c, r), s); break;
     default: return GLABC_ERR_DIM;
     }
+    if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
+    return rc;
 }
 
 template <int OP>
@@ -480,14 +419,14 @@ __attribute__((visibility("default"))) int glabc_glmcmc_steps(const glabc_model*
                                                               const glabc_dist* importance, const glabc_chains* chains,
                                                               const glabc_run* run, void* stream)
 {
-    return run_sampler<ALGO_GLMCMC>(model, local, importance, chains, run, stream);
+    return run_sampler(ALGO_GLMCMC, model, local, importance, chains, run, stream);
 }
 
 __attribute__((visibility("default"))) int glabc_globalmcmc_steps(const glabc_model* model, const glabc_dist* local,
                                                                   const glabc_dist* global, const glabc_chains* chains,
                                                                   const glabc_run* run, void* stream)
 {
-    return run_sampler<ALGO_GLOBAL>(model, local, global, chains, run, stream);
+    return run_sampler(ALGO_GLOBAL, model, local, global, chains, run, stream);
 }
 
 __attribute__((visibility("default"))) int glabc_init_weights(const glabc_model* model, const glabc_dist* importance,
@@ -605,6 +544,26 @@ __attribute__((visibility("default"))) int glabc_moments_esjd(const glabc_moment
     case 3: hipLaunchKernelGGL(moments_esjd_kernel<3>, grid, block, 0, s, moments->sum_jump, n_steps, n_chains, stride, esjd_out); break;
     case 4: hipLaunchKernelGGL(moments_esjd_kernel<4>, grid, block, 0, s, moments->sum_jump, n_steps, n_chains, stride, esjd_out); break;
     }
+    return finish_launch();
+}
+
+/* Test hooks: evaluate include/glabc_numerics.h ON THE DEVICE so the tests can require bit equality
+ * with the host evaluation (the premise of every bit-parity claim).  Not part of the sampling API. */
+__attribute__((visibility("default"))) int glabc_selftest_numerics(int op, const uint32_t* in, uint32_t* out, int64_t n, void* stream)
+{
+    if (!in || !out) return GLABC_ERR_NULL;
+    if (op < 0 || op > 5 || n < 0) return GLABC_ERR_ARG;
+    if (n == 0) return GLABC_OK;
+    hipLaunchKernelGGL(numerics_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, op, in, out, n);
+    return finish_launch();
+}
+
+__attribute__((visibility("default"))) int glabc_selftest_sqrt(uint32_t first_bits, uint32_t last_bits, uint64_t* mismatches, void* stream)
+{
+    if (!mismatches) return GLABC_ERR_NULL;
+    if (last_bits < first_bits) return GLABC_ERR_ARG;
+    hipLaunchKernelGGL(sqrt_check_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, first_bits, last_bits,
+                       (unsigned long long*)mismatches);
     return finish_launch();
 }
 

@@ -100,6 +100,8 @@ class Run(C.Structure):
         ("hist_stride", C.c_int64),
         ("moments", C.POINTER(Moments)),
         ("tape", C.POINTER(Tape)),
+        ("lanes_per_chain", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -116,6 +118,8 @@ ENTRY_POINTS = {
     "glabc_model_log_kernel": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_esjd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_moments_esjd": (C.c_int, [_P(Moments), C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_selftest_numerics": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "glabc_selftest_sqrt": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "glabc_version": (C.c_int, []),
     "glabc_status_string": (C.c_char_p, [C.c_int]),
     "glabc_last_hip_error": (C.c_int, []),

@@ -120,11 +120,13 @@ class Moments:
 
 
 def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0, seed, global_frequency, batch_size,
-              history=None, moments=None, steps_per_launch=None):
+              history=None, moments=None, steps_per_launch=None, lanes_per_chain=0):
     """Advance `chains` by n_steps iterations with the C-ABI entry point `entry`
     ('glabc_glmcmc_steps' / 'glabc_globalmcmc_steps'), K iterations per launch.
 
     history: None or float32 tensor [n_steps][d][C] on the chains' device.
+    lanes_per_chain: 0 = let the library choose from the chain count; 1 / 2 / 4 force the
+    launch geometry (results are identical for every choice).
     """
     lib = _capi.lib()
     fn = getattr(lib, entry)
@@ -142,6 +144,7 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
             run.n_steps = k
             run.global_frequency = float(global_frequency)
             run.batch_size = int(batch_size or 1)
+            run.lanes_per_chain = int(lanes_per_chain)
             if history is not None:
                 run.history = history[done].data_ptr()
                 run.hist_stride = chains.n

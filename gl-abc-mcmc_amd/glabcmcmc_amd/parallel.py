@@ -1,0 +1,72 @@
+"""Multi-GPU: chains shard embarrassingly.
+
+Rank r of W owns the global chain ids [r*C, (r+1)*C) -- ``chain0 = r*C`` in
+``glabc_chains`` -- and because the Philox counter carries the GLOBAL chain id a W-GPU
+run is, bit for bit, the concatenation of W single-GPU runs.  Nothing is exchanged while
+sampling.  The only collective is one all-gather (RCCL over xGMI when the backend is
+"nccl") of the per-chain streaming sums at checkpoint / ESJD time: per chain
+d + 2*tri(d) float64 words (64 B for d = 2; 4 MiB per GPU at 65 536 chains) --
+latency-bound, one call, no bucketing needed.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _capi, engine
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous chain-id range of `rank`: (chain0, n_local); remainders go to the low ranks."""
+    base, rem = divmod(int(n_total), int(world))
+    n_local = base + (1 if rank < rem else 0)
+    chain0 = rank * base + min(rank, rem)
+    return chain0, n_local
+
+
+def gather_rows(local_rows, world):
+    """All-gather equally-sized per-rank blocks [k][n] (chain-major) into [k][world*n],
+    ranks in order, i.e. in global chain-id order.  Works on any backend (gloo on CPU
+    tensors in the tests, nccl = RCCL on device tensors in production)."""
+    if world == 1:
+        return local_rows
+    k, n = local_rows.shape
+    out = torch.empty(world * k, n, dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(out, local_rows.contiguous())
+    return out.view(world, k, n).permute(1, 0, 2).reshape(k, world * n).contiguous()
+
+
+def gather_moments(mom, world):
+    """engine.Moments of ALL chains of the job (every rank gets the same object)."""
+    if world == 1:
+        return mom
+    d = mom.d
+    tri = d * (d + 1) // 2
+    packed = torch.cat([mom.sum_theta, mom.sum_outer, mom.sum_jump], dim=0)        # [d + 2 tri][n]
+    allrows = gather_rows(packed, world)
+    out = engine.Moments.__new__(engine.Moments)
+    out.n, out.d, out.steps = mom.n * world, d, mom.steps
+    out.sum_theta = allrows[:d].contiguous()
+    out.sum_outer = allrows[d:d + tri].contiguous()
+    out.sum_jump = allrows[d + tri:].contiguous()
+    return out
+
+
+def gather_chain_stats(mom, world):
+    """Per-chain ESJD (ESJD.py:21-24, via glabc_moments_esjd) and pooled posterior moments
+    of the whole job from the all-gathered streaming sums."""
+    allm = gather_moments(mom, world)
+    steps = float(allm.steps)
+    return {
+        "esjd": allm.esjd(),
+        "mean": float((allm.sum_theta.sum(dim=1) / (steps * allm.n)).mean()),
+        "mean_sq": float(torch.stack([allm.sum_outer[k].sum() for k in _diag(allm.d)]).mean() / (steps * allm.n)),
+        "n_chains": allm.n,
+    }
+
+
+def _diag(d):
+    """positions of the diagonal entries in the row-major upper triangle"""
+    pos, k = [], 0
+    for p in range(d):
+        pos.append(k)
+        k += d - p
+    return pos

@@ -137,6 +137,9 @@ typedef struct glabc_run {
     int64_t hist_stride;           /* >= n_chains */
     const glabc_moments* moments;  /* NULL or accumulators (same stride as chains) */
     const glabc_tape* tape;        /* NULL = Philox */
+    int32_t lanes_per_chain;       /* launch geometry only, never changes results: 0 = choose from n_chains,
+                                      or 1 / 2 / 4 lanes cooperating on one chain's batch_size proposals */
+    int32_t reserved;
 } glabc_run;
 
 /* ---- entry points ------------------------------------------------------------ */
@@ -175,6 +178,14 @@ int glabc_esjd(const float* history, int64_t n_rows, int32_t theta_dim, int64_t 
  * iterations): esjd[c] = det(sum_jump_c / n_steps)^(1/theta_dim).  No history needed. */
 int glabc_moments_esjd(const glabc_moments* moments, int64_t n_steps, int32_t theta_dim, int64_t n_chains,
                        int64_t stride, float* esjd_out, void* stream);
+
+/* Test hooks (not part of the sampling API): evaluate include/glabc_numerics.h on the device.
+ * op 0 expf, 1 logf, 2 sin(2 pi u), 3 cos(2 pi u) on float bit patterns in[n] -> out[n];
+ * op 4 / 5: the two normals of glabc_normal_pair(in[2i], in[2i+1]).  glabc_selftest_sqrt counts the
+ * floats with bit pattern in [first_bits, last_bits] whose glabc_sqrtf_normal differs from the
+ * exactly rounded square root (*mismatches is a device counter the caller zeroed). */
+int glabc_selftest_numerics(int op, const uint32_t* in, uint32_t* out, int64_t n, void* stream);
+int glabc_selftest_sqrt(uint32_t first_bits, uint32_t last_bits, uint64_t* mismatches, void* stream);
 
 int glabc_version(void);
 const char* glabc_status_string(int status);

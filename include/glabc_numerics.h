@@ -32,6 +32,15 @@
 #define GLABC_HD static inline
 #endif
 
+/* the 10 Philox rounds are straight-line code: independent calls then interleave (ILP) */
+#if defined(__clang__)
+#define GLABC_UNROLL_10 _Pragma("unroll")
+#elif defined(__GNUC__)
+#define GLABC_UNROLL_10 _Pragma("GCC unroll 10")
+#else
+#define GLABC_UNROLL_10
+#endif
+
 /* ---- bit casts ---------------------------------------------------------- */
 GLABC_HD uint32_t glabc_f2u(float x) { uint32_t u; __builtin_memcpy(&u, &x, 4); return u; }
 GLABC_HD float glabc_u2f(uint32_t u) { float x; __builtin_memcpy(&x, &u, 4); return x; }
@@ -54,6 +63,7 @@ typedef struct { uint32_t v[4]; } glabc_u32x4;
 GLABC_HD glabc_u32x4 glabc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                          uint32_t k0, uint32_t k1)
 {
+GLABC_UNROLL_10
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)GLABC_PHILOX_M0 * c0;
         uint64_t p1 = (uint64_t)GLABC_PHILOX_M1 * c2;
@@ -85,15 +95,12 @@ GLABC_HD double glabc_uniform_f64(uint32_t a, uint32_t b)
 
 /* ---- f32 log ---------------------------------------------------------------
  * x = 2^e * m, m in [sqrt(1/2), sqrt(2)); log m = f - f^2/2 + f^3 P(f), f = m-1.
- * Max error < 1 ulp + rounding of the final sums (measured: tests/test_numerics.py). */
-GLABC_HD float glabc_logf(float x)
+ * Max error < 1 ulp (measured exhaustively on (0,1] and sampled elsewhere:
+ * tests/test_numerics.py).  glabc_logf_normal is the branch-free core for positive
+ * NORMAL finite x; glabc_logf adds the IEEE special cases and subnormals around it
+ * and returns the same bits wherever both apply. */
+GLABC_HD float glabc_logf_core(uint32_t ix, float escale)
 {
-    uint32_t ix = glabc_f2u(x);
-    float escale = 0.0f;
-    if (ix == 0u || ix == 0x80000000u) return -__builtin_inff();        /* log(+-0) = -inf */
-    if (ix >> 31) return __builtin_nanf("");                             /* log(<0) = nan (nan with sign bit too) */
-    if (ix >= 0x7f800000u) return x;                                     /* +inf, nan */
-    if (ix < 0x00800000u) { x = x * 0x1p23f; ix = glabc_f2u(x); escale = -23.0f; }
     ix += 0x3f800000u - 0x3f3504f3u;
     float e = (float)((int32_t)(ix >> 23) - 127) + escale;
     float m = glabc_u2f((ix & 0x007fffffu) + 0x3f3504f3u);
@@ -111,6 +118,42 @@ GLABC_HD float glabc_logf(float x)
     r = __builtin_fmaf(-0.5f, f2, r);
     r = r + f;
     return __builtin_fmaf(e, 0x1.62e4p-1f, r);                  /* + e*ln2_hi (ln2_hi has 9 trailing zero bits: e*ln2_hi exact) */
+}
+
+GLABC_HD float glabc_logf_normal(float x) { return glabc_logf_core(glabc_f2u(x), 0.0f); }
+
+GLABC_HD float glabc_logf(float x)
+{
+    uint32_t ix = glabc_f2u(x);
+    float escale = 0.0f;
+    if (ix == 0u || ix == 0x80000000u) return -__builtin_inff();        /* log(+-0) = -inf */
+    if (ix >> 31) return __builtin_nanf("");                             /* log(<0) = nan (nan with sign bit too) */
+    if (ix >= 0x7f800000u) return x;                                     /* +inf, nan */
+    if (ix < 0x00800000u) { x = x * 0x1p23f; ix = glabc_f2u(x); escale = -23.0f; }
+    return glabc_logf_core(ix, escale);
+}
+
+/* ---- f32 sqrt of x that is +-0 or finite with x >= 2^-64 ------------------------
+ * Correctly rounded (== IEEE sqrtf, which is what the host build calls).  On gfx950 the
+ * compiler's sqrtf expansion spends a third of its instructions on the rescaling of tiny
+ * arguments (whose residuals would underflow) and on class checks; Box-Muller's argument is
+ * 0 or in [1e-7, 46], so the device build keeps only the hardware estimate and the one-ulp
+ * correction step.  Checked against the exactly rounded (float)sqrt((double)x) for EVERY
+ * float in [2^-64, FLT_MAX] and for +-0 on the GPU (tests/test_hip_numerics.py). */
+GLABC_HD float glabc_sqrtf_normal(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float s = __builtin_amdgcn_sqrtf(x);
+    float s_dn = glabc_u2f(glabc_f2u(s) - 1u);
+    float s_up = glabc_u2f(glabc_f2u(s) + 1u);
+    float r_dn = __builtin_fmaf(-s_dn, s, x);
+    float r_up = __builtin_fmaf(-s_up, s, x);
+    s = (r_dn <= 0.0f) ? s_dn : s;
+    s = (r_up > 0.0f) ? s_up : s;
+    return s;
+#else
+    return __builtin_sqrtf(x);
+#endif
 }
 
 /* ---- f32 exp ---------------------------------------------------------------
@@ -169,7 +212,7 @@ GLABC_HD void glabc_sincos2pi(float u, float* s_out, float* c_out)
 GLABC_HD void glabc_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1)
 {
     float u1 = glabc_uniform_pos_f32(a);
-    float rad = __builtin_sqrtf(-2.0f * glabc_logf(u1));
+    float rad = glabc_sqrtf_normal(-2.0f * glabc_logf_normal(u1));   /* u1 in [2^-33, 1]: argument is 0 or in [1e-7, 46] */
     float s, c;
     glabc_sincos2pi(glabc_uniform_f32(b), &s, &c);
     *z0 = rad * c;

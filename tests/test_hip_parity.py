@@ -20,7 +20,7 @@ ENTRY = {"glmcmc": "glabc_glmcmc_steps", "globalmcmc": "glabc_globalmcmc_steps"}
 
 
 def hip_run(algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=0, steps_per_launch=None, moments=False,
-            step0=1, chains=None, history=True):
+            step0=1, chains=None, history=True, lanes=0):
     from glabcmcmc_amd import engine
     dev = torch.device("cuda", 0)
     if chains is None:
@@ -30,7 +30,7 @@ def hip_run(algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=0, step
     hist = torch.empty(T, chains.d, chains.n, dtype=torch.float32, device=dev) if history else None
     mom = engine.Moments(chains.n, chains.d, dev) if moments else None
     engine.run_steps(ENTRY[algo], model, local, glob, chains, T, step0, seed, gf, N, history=hist, moments=mom,
-                     steps_per_launch=steps_per_launch)
+                     steps_per_launch=steps_per_launch, lanes_per_chain=lanes)
     torch.cuda.synchronize()
     return (hist.cpu().numpy() if history else None), chains, mom
 
@@ -113,6 +113,24 @@ def test_hip_equals_oracle(hip, oracle, case):
     assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 6, 8, 13, 16])
+def test_lanes_per_chain_is_only_geometry(hip, oracle, N, lanes):
+    """1, 2 or 4 lanes cooperating on a chain (glabc_run.lanes_per_chain) give the oracle's bits."""
+    cfg = dict(epsilon=0.2, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0.1, -0.1], [1.0, 1.25])})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(1000 * N + lanes)
+    n, T = 333, 120
+    theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, 2))).astype(np.float32)
+    hist, chains, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, 7 + N, 0.75, N, chain0=3, lanes=lanes)
+    hh, hc, _ = oracle_run(oracle, "glmcmc", model, local, glob, theta0, y0, T, 7 + N, 0.75, N, chain0=3)
+    same = bits(hist) == bits(hh)
+    assert same.all(), "first mismatch at (t, dim, chain) = %s" % (np.argwhere(~same)[0],)
+    assert_same_state(chains, hc, True)
+    assert hc.n_moves.sum() > 0
+
+
 @pytest.mark.parametrize("d", [1, 3, 4])
 def test_other_dimensions(hip, oracle, d):
     """theta_dim 1, 3, 4 (the Model is |theta| + noise in any dimension)."""
@@ -133,8 +151,8 @@ def test_other_dimensions(hip, oracle, d):
     n, T, N = 1030, 150, 5
     theta0 = rng.standard_normal((n, d)).astype(np.float32)
     y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
-    for algo in ("glmcmc", "globalmcmc"):
-        hist, chains, _ = hip_run(algo, model, local, glob, theta0, y0, T, 99 + d, 0.6, N)
+    for algo, lanes in (("glmcmc", 1), ("glmcmc", 2), ("glmcmc", 4), ("globalmcmc", 0)):
+        hist, chains, _ = hip_run(algo, model, local, glob, theta0, y0, T, 99 + d, 0.6, N, lanes=lanes)
         hh, hc, _ = oracle_run(oracle, algo, model, local, glob, theta0, y0, T, 99 + d, 0.6, N)
         assert np.array_equal(bits(hist), bits(hh))
         assert_same_state(chains, hc, algo == "glmcmc")
@@ -313,5 +331,9 @@ def test_full_size_bit_parity_and_posterior(hip, oracle):
     full = torch.cat([start[None], torch.from_numpy(hist).cuda()], dim=0)
     e_hist = esjd_per_chain(full).cpu().numpy().astype(np.float64)
     e_mom = mom.esjd().cpu().numpy().astype(np.float64)
-    assert abs(e_hist.mean() - e_mom.mean()) / e_hist.mean() < 1e-3
-    assert 0.001 < e_hist.mean() < 1.0
+    # a chain with fewer than two independent jumps has a singular jump matrix: det = +-rounding,
+    # and det ** (1/2) is NaN for the negative ones -- in ESJD.py:24 as well as here
+    ok = np.isfinite(e_hist) & np.isfinite(e_mom)
+    assert ok.mean() > 0.97
+    assert abs(e_hist[ok].mean() - e_mom[ok].mean()) / e_hist[ok].mean() < 1e-3
+    assert 0.001 < e_hist[ok].mean() < 1.0

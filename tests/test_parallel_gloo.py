@@ -1,0 +1,69 @@
+"""world_size-2 test of the multi-GPU plumbing on CPU (gloo): shard ranges, the
+all-gather of per-chain sums in global chain-id order."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glabcmcmc_amd import engine
+        from glabcmcmc_amd.parallel import gather_moments, gather_rows, shard_range
+        chain0, n = shard_range(n_total, rank, world)
+        ids = torch.arange(chain0, chain0 + n, dtype=torch.float64)
+        rows = torch.stack([ids, ids * 10 + 1, -ids])                       # [k=3][n], value encodes the chain id
+        allrows = gather_rows(rows, world)
+        mom = engine.Moments.__new__(engine.Moments)
+        mom.n, mom.d, mom.steps = n, 2, 7
+        mom.sum_theta = torch.stack([ids, ids + 0.5])
+        mom.sum_outer = torch.stack([ids * 2, ids * 3, ids * 4])
+        mom.sum_jump = torch.stack([ids * 5, ids * 6, ids * 7])
+        allm = gather_moments(mom, world)
+        q.put((rank, chain0, n, allrows, allm.n, allm.steps, allm.sum_theta, allm.sum_outer, allm.sum_jump))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_in_chain_id_order():
+    world, n_total = 2, 64
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ids = torch.arange(n_total, dtype=torch.float64)
+    assert [(r[1], r[2]) for r in res] == [(0, 32), (32, 32)]
+    for r in res:
+        assert torch.equal(r[3], torch.stack([ids, ids * 10 + 1, -ids]))
+        assert r[4] == n_total and r[5] == 7
+        assert torch.equal(r[6], torch.stack([ids, ids + 0.5]))
+        assert torch.equal(r[7], torch.stack([ids * 2, ids * 3, ids * 4]))
+        assert torch.equal(r[8], torch.stack([ids * 5, ids * 6, ids * 7]))
+
+
+def test_shard_range_covers_everything():
+    from glabcmcmc_amd.parallel import shard_range
+    for n_total in (1, 7, 64, 65536, 524288, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_range(n_total, r, world) for r in range(world)]
+            assert spans[0][0] == 0
+            for (a, n), (b, _) in zip(spans, spans[1:]):
+                assert a + n == b
+            assert spans[-1][0] + spans[-1][1] == n_total
+            assert max(s[1] for s in spans) - min(s[1] for s in spans) <= 1
