@@ -19,6 +19,9 @@ DIST_GAMMA = 2
 SIM_ABS_GAUSS = 0
 
 FLAG_LOCAL = 1
+FLAG_TH64 = 2
+FLAG_LW64 = 4
+FLAG_HAS_GRAD = 8
 
 OK = 0
 
@@ -65,6 +68,21 @@ class Chains(C.Structure):
         ("log_w", C.c_void_p),
         ("flags", C.c_void_p),
         ("n_moves", C.c_void_p),
+        ("theta64", C.c_void_p),
+        ("y64", C.c_void_p),
+        ("log_w64", C.c_void_p),
+        ("grad", C.c_void_p),
+    ]
+
+
+class Mala(C.Structure):
+    """struct glabc_mala"""
+    _fields_ = [
+        ("tau", C.c_double),
+        ("tau_sq", C.c_double),
+        ("eps_sq", C.c_double),
+        ("num_grad", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -93,6 +93,14 @@ typedef struct glabc_model {
 
 /* ---- chain state ----------------------------------------------------------- */
 #define GLABC_FLAG_LOCAL 1u        /* the reference's `local` dirty flag, GLMCMC.py:50,65,100 */
+/* GLMALA only.  The reference's tensors change dtype while a chain runs: the gradient estimate is
+ * float64 (GLMALA.py:70-72), so the first ACCEPTED MALA move turns Theta_old / y_old into float64
+ * tensors (GLMALA.py:43,197-198) and every later torch.cat keeps them float64; log_weight_old takes
+ * the dtype the state has when it is first computed (GLMALA.py:152-156) and keeps it.  The two
+ * sticky bits below record in which precision the reference would be computing. */
+#define GLABC_FLAG_TH64 2u         /* Theta_old, y_old are float64 tensors */
+#define GLABC_FLAG_LW64 4u         /* log_weight_old (and hence the iSIR weights) are float64 */
+#define GLABC_FLAG_HAS_GRAD 8u     /* grad_logABC_Theta_old is not None, GLMALA.py:146,183-184 */
 
 typedef struct glabc_chains {
     int64_t n_chains;              /* chains in this call (this GPU's shard) */
@@ -103,6 +111,13 @@ typedef struct glabc_chains {
     float* log_w;                  /* [stride] log_weight_old GLMCMC.py:53-55 (iSIR samplers; else NULL) */
     uint32_t* flags;               /* [stride] GLABC_FLAG_* (iSIR samplers; else NULL) */
     uint32_t* n_moves;             /* [stride] accepted moves, num_acc GLMCMC.py:51,88,101; NULL = not counted */
+    /* GLMALA state (NULL for the other samplers): the authoritative copy of the state in double
+     * (float32-exact values while the corresponding GLABC_FLAG_*64 bit is clear); theta / y above
+     * then receive the float32 casts that Theta_Re records (GLMALA.py:180,200) */
+    double* theta64;               /* [theta_dim][stride] */
+    double* y64;                   /* [y_dim][stride] */
+    double* log_w64;               /* [stride] */
+    double* grad;                  /* [theta_dim][stride] grad_logABC_Theta_old, GLMALA.py:146,199 */
 } glabc_chains;
 
 /* Per-chain streaming sums for ESJD.py:17-24 and posterior moments, updated
@@ -153,6 +168,26 @@ int glabc_glmcmc_steps(const glabc_model* model, const glabc_dist* local, const 
 /* GlobalMCMC.py:37-68 -- independence MH global move / random-walk MH local move. */
 int glabc_globalmcmc_steps(const glabc_model* model, const glabc_dist* local, const glabc_dist* global,
                            const glabc_chains* chains, const glabc_run* run, void* stream);
+
+/* GLMALA.py:150-200 -- iSIR global move (GLMALA.py:151-180) / MALA local move whose drift is the
+ * common-random-number central-difference gradient of a synthetic-likelihood log-ABC
+ * (numberical_gradient_logABC, GLMALA.py:46-95; Local_proposal_forward :25-44; log_proposal :97-116).
+ * tau_sq = tau**2 and eps_sq = epsilon**2 are passed as the caller's double-precision values
+ * (Python evaluates them in float, GLMALA.py:43,90).  chains->theta64 / y64 / log_w64 / grad are
+ * required; initialise them with glabc_glmala_init. */
+typedef struct glabc_mala {
+    double tau;                    /* GLMALA.py:118 */
+    double tau_sq;                 /* tau ** 2 */
+    double eps_sq;                 /* ABCset.epsilon ** 2 */
+    int32_t num_grad;              /* simulations per finite-difference side, GLMALA.py:46 `num` */
+    int32_t reserved;
+} glabc_mala;
+
+int glabc_glmala_steps(const glabc_model* model, const glabc_dist* importance, const glabc_mala* mala,
+                       const glabc_chains* chains, const glabc_run* run, void* stream);
+
+/* GLMALA.py:143-149: theta64 / y64 <- theta / y, flags <- LOCAL, no gradient yet. */
+int glabc_glmala_init(const glabc_model* model, const glabc_chains* chains, void* stream);
 
 /* GLMCMC.py:52-55 -- (re)initialise log_w = prior + log-kernel - q(theta) and set
  * GLABC_FLAG_LOCAL for every chain. */

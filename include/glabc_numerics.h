@@ -219,4 +219,62 @@ GLABC_HD void glabc_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1)
     *z1 = rad * s;
 }
 
+/* ---- f64 log / exp (GLMALA only: its gradient estimate and, once a chain has switched to
+ * float64, its iSIR weights are float64 in the reference, GLMALA.py:70-95,166-169) --------------
+ * The classic fdlibm algorithms (Sun Microsystems, freely distributable) restated with their
+ * published constants; < 1 ulp.  Plain IEEE double + - * / only, so host and device agree
+ * bit for bit under -ffp-contract=off. */
+#define GLABC_LOG_2PI 1.8378770664093453      /* numpy.log(2*numpy.pi), distribution.py:171 in float64 */
+
+GLABC_HD double glabc_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t ix = glabc_d2u(x);
+    int64_t k = 0;
+    if ((ix << 1) == 0) return -__builtin_inf();                /* log(+-0) */
+    if (ix >> 63) return __builtin_nan("");                      /* log(<0), nan with sign */
+    if (ix >= 0x7ff0000000000000ull) return x;                   /* +inf, nan */
+    if (ix < 0x0010000000000000ull) { x = x * 0x1p54; ix = glabc_d2u(x); k = -54; }
+    /* normalise so that 1+f is in [sqrt(2)/2, sqrt(2)) */
+    uint64_t hx = ix + (0x3ff0000000000000ull - 0x3fe6a09e667f3bcdull);
+    k += (int64_t)(hx >> 52) - 1023;
+    ix = (hx & 0x000fffffffffffffull) + 0x3fe6a09e667f3bcdull;
+    double f = glabc_u2d(ix) - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s, w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+GLABC_HD double glabc_exp(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 709.782712893383973096) return __builtin_inf();
+    if (x < -745.13321910194110842) return 0.0;
+    double kf = invln2 * x + (x < 0.0 ? -0.5 : 0.5);
+    int32_t k = (int32_t)kf;                                     /* truncation toward zero */
+    double dk = (double)k;
+    double hi = x - dk * ln2HI, lo = dk * ln2LO;
+    double r = hi - lo;
+    double t = r * r;
+    double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    /* scale by 2^k in two steps (k in [-1075, 1024]) so the subnormal range rounds once */
+    int32_t k1 = k / 2, k2 = k - k1;
+    double s1 = glabc_u2d((uint64_t)(k1 + 1023) << 52);
+    double s2 = glabc_u2d((uint64_t)(k2 + 1023) << 52);
+    return (y * s1) * s2;
+}
+
 #endif /* GLABC_NUMERICS_H */

@@ -565,6 +565,385 @@ ORACLE_API int oracle_globalmcmc_steps(const glabc_model* m, const glabc_dist* l
     return 0;
 }
 
+
+/* ========================================================================= */
+/* GLMALA.py:8-230                                                            */
+/* ========================================================================= */
+
+/* ATen's float64 sum over a contiguous row (same scheme as float32 with 4-wide vectors;
+ * probed on the reference's torch build): n < 4 sequential; else four lanes of 4-wide vectors,
+ * leftover vectors into lane 0, lanes combined left to right, then a scalar accumulator takes
+ * the n%4 tail in order followed by the 4 vector partials in order. */
+static double aten_rowsum_f64(const double* x, int n)
+{
+    if (n <= 0) return 0.0;
+    if (n < 4) {
+        double s = x[0];
+        for (int i = 1; i < n; ++i) s = s + x[i];
+        return s;
+    }
+    int nv = n / 4, g = nv / 4;
+    double acc[4];
+    if (g == 0) {
+        for (int k = 0; k < 4; ++k) acc[k] = x[k];
+        for (int v = 1; v < nv; ++v)
+            for (int k = 0; k < 4; ++k) acc[k] = acc[k] + x[4 * v + k];
+    } else {
+        double l[4][4];
+        for (int q = 0; q < 4; ++q)
+            for (int k = 0; k < 4; ++k) l[q][k] = x[4 * q + k];
+        for (int i = 1; i < g; ++i)
+            for (int q = 0; q < 4; ++q)
+                for (int k = 0; k < 4; ++k) l[q][k] = l[q][k] + x[4 * (4 * i + q) + k];
+        for (int v = 4 * g; v < nv; ++v)
+            for (int k = 0; k < 4; ++k) l[0][k] = l[0][k] + x[4 * v + k];
+        for (int k = 0; k < 4; ++k) acc[k] = ((l[0][k] + l[1][k]) + l[2][k]) + l[3][k];
+    }
+    double fa = 0.0;
+    for (int i = 4 * nv; i < n; ++i) fa = fa + x[i];
+    for (int k = 0; k < 4; ++k) fa = fa + acc[k];
+    return fa;
+}
+
+ORACLE_API double oracle_aten_rowsum_f64(const double* x, int n) { return aten_rowsum_f64(x, n); }
+
+/* distribution.py:176-181 / 81-86 evaluated on a float64 tensor: the float32 parameters are
+ * promoted, the constant -0.5*d*log(2 pi) stays a float64 scalar; Uniform.log_prob builds its
+ * result from float32 ones (distribution.py:82), so it stays a float32 value. */
+static double dist_log_prob_f64(const glabc_dist* g, const double* z)
+{
+    if (g->kind == GLABC_DIST_DIAG_GAUSS) {
+        double t[GLABC_MAX_DIM];
+        for (int j = 0; j < g->dim; ++j) {
+            double e = (z[j] - (double)g->p0[j]) / (double)g->p2[j];
+            t[j] = (double)g->p1[j] + 0.5 * (e * e);
+        }
+        return (-0.5 * (double)g->dim * GLABC_LOG_2PI) - aten_rowsum_f64(t, g->dim);
+    }
+    for (int j = 0; j < g->dim; ++j)
+        if (z[j] < (double)g->p0[j] || z[j] > (double)g->p1[j]) return -INFINITY;
+    return (double)g->c0;
+}
+
+/* Mixture.py:33-45 on a float64 y */
+static double model_log_kernel_f64(const glabc_model* m, const double* y)
+{
+    double t[GLABC_MAX_DIM];
+    for (int j = 0; j < m->y_dim; ++j) {
+        double d = y[j] - (double)m->y_obs[j];
+        t[j] = d * d;
+    }
+    double dis = sqrt(aten_rowsum_f64(t, m->y_dim));
+    double e = (dis - 0.0) / (double)m->kern_scale;
+    return (-0.5 * 1.0 * GLABC_LOG_2PI) - ((double)m->kern_log_scale + 0.5 * (e * e));
+}
+
+typedef struct mala_state {
+    double theta[GLABC_MAX_DIM];   /* float32-exact while !(flags & TH64) */
+    double y[GLABC_MAX_DIM];
+    double log_w;                  /* float32-exact while !(flags & LW64) */
+    double grad[GLABC_MAX_DIM];
+    uint32_t flags, n_moves;
+} mala_state;
+
+/* prior / kernel / importance density of the CURRENT state in the precision the reference's
+ * tensors have at this point */
+static double state_prior(const glabc_model* m, const mala_state* s)
+{
+    if (s->flags & GLABC_FLAG_TH64) return dist_log_prob_f64(&m->prior, s->theta);
+    float th[GLABC_MAX_DIM];
+    for (int j = 0; j < m->theta_dim; ++j) th[j] = (float)s->theta[j];
+    return (double)model_prior(m, th);
+}
+
+static double state_kernel(const glabc_model* m, const mala_state* s)
+{
+    if (s->flags & GLABC_FLAG_TH64) return model_log_kernel_f64(m, s->y);
+    float y[GLABC_MAX_DIM];
+    for (int j = 0; j < m->y_dim; ++j) y[j] = (float)s->y[j];
+    return (double)model_log_kernel(m, y);
+}
+
+/* the standard-normal noise of one gradient simulation: Philox slots beyond the candidates' --
+ * GRAD_BASE + g*GRAD_STRIDE + block, normal index n = (k*num + s)*y_dim + j lives in block n/4,
+ * Box-Muller pair (n%4)/2, element n%2.  g = 0: gradient at Theta_old (first local move only),
+ * g = 1: gradient at the proposal.  The +d and -d simulations of a coordinate share their noise
+ * (the reference reseeds torch with the same seed, GLMALA.py:76,80). */
+#define GRAD_BASE 0x100000u
+#define GRAD_STRIDE 0x80000u
+
+static void grad_noise(uint64_t seed, uint64_t chain, uint32_t step, int g, int k, int s, int num, int yd, float* eps)
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)chain, c1 = (uint32_t)(chain >> 32);
+    for (int j = 0; j < yd; ++j) {
+        int64_t n = ((int64_t)k * num + s) * yd + j;
+        uint32_t slot = GRAD_BASE + (uint32_t)g * GRAD_STRIDE + (uint32_t)(n / 4);
+        glabc_u32x4 r = glabc_philox4x32_10(c0, c1, step, slot, k0, k1);
+        int p = (int)((n % 4) / 2);
+        float z0, z1;
+        glabc_normal_pair(r.v[2 * p], r.v[2 * p + 1], &z0, &z1);
+        eps[j] = (n % 2) ? z1 : z0;
+    }
+}
+
+ORACLE_API void oracle_grad_noise(uint64_t seed, uint64_t chain, uint32_t step, int g, int k, int num, int yd, float* out)
+{
+    for (int s = 0; s < num; ++s) grad_noise(seed, chain, step, g, k, s, num, yd, out + (int64_t)s * yd);
+}
+
+/* numberical_gradient_logABC, GLMALA.py:46-95, for one theta (already cast to float32, :62).
+ * mean / unbiased variance of the num discrepancies are accumulated in double on data shifted by
+ * the first sample (torch.mean / torch.var use their own cascades; the results agree to ~1e-16
+ * relative, far below anything a float32 chain value can see). */
+static void numerical_gradient(const glabc_model* m, const glabc_mala* p, const float* theta, uint64_t seed,
+                               uint64_t chain, uint32_t step, int g, double* grad)
+{
+    int d = m->theta_dim, yd = m->y_dim, num = p->num_grad;
+    const float h = 0.1f;                                   /* d = 1e-1 as a float32 eye entry, :65 */
+    const float hp = 0.00001f;                              /* :84 */
+    for (int k = 0; k < d; ++k) {
+        float tp[GLABC_MAX_DIM], tm[GLABC_MAX_DIM];
+        for (int j = 0; j < d; ++j) {
+            tp[j] = theta[j] + (j == k ? h : 0.0f);         /* :67 */
+            tm[j] = theta[j] - (j == k ? h : 0.0f);         /* :68 */
+        }
+        double c_p = 0.0, c_m = 0.0, s1p = 0.0, s2p = 0.0, s1m = 0.0, s2m = 0.0;
+        for (int s = 0; s < num; ++s) {
+            float eps[GLABC_MAX_DIM], yp[GLABC_MAX_DIM], ym[GLABC_MAX_DIM];
+            grad_noise(seed, chain, step, g, k, s, num, yd, eps);
+            model_simulate(m, tp, eps, yp);                 /* :78 */
+            model_simulate(m, tm, eps, ym);                 /* :82 (same noise) */
+            double dp = (double)model_discrepancy(m, yp), dm = (double)model_discrepancy(m, ym);
+            if (s == 0) { c_p = dp; c_m = dm; }
+            double ep = dp - c_p, em = dm - c_m;
+            s1p += ep; s2p += ep * ep;
+            s1m += em; s2m += em * em;
+        }
+        double n = (double)num;
+        double mu_p = c_p + s1p / n, mu_m = c_m + s1m / n;                              /* :86-87 */
+        double var_p = (s2p - (s1p * s1p) / n) / (n - 1.0), var_m = (s2m - (s1m * s1m) / n) / (n - 1.0);   /* :88-89 */
+        double lp = (-0.5 * glabc_log(var_p + p->eps_sq)) - ((0.5 * (mu_p * mu_p)) / (var_p + p->eps_sq));   /* :90-91 */
+        double lm = (-0.5 * glabc_log(var_m + p->eps_sq)) - ((0.5 * (mu_m * mu_m)) / (var_m + p->eps_sq));   /* :92-93 */
+        double gll = (lp - lm) / 0.2;                                                   /* :94, 2*d */
+        for (int j = 0; j < d; ++j) {
+            tp[j] = theta[j] + (j == k ? hp : 0.0f);                                    /* :84 */
+            tm[j] = theta[j] - (j == k ? hp : 0.0f);
+        }
+        float gp = (model_prior(m, tp) - model_prior(m, tm)) / 0.00002f;                /* :84-85, float32 */
+        grad[k] = gll + (double)gp;                                                     /* :95 */
+    }
+}
+
+ORACLE_API int oracle_numerical_gradient(const glabc_model* m, const glabc_mala* p, const float* theta, uint64_t seed,
+                                         uint64_t chain, uint32_t step, int g, double* grad)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    numerical_gradient(m, p, theta, seed, chain, step, g, grad);
+    return 0;
+}
+
+/* the MALA local move, GLMALA.py:182-200 */
+static int mala_move(const glabc_model* m, const glabc_mala* p, mala_state* s, const step_draws* dr, uint64_t seed,
+                     uint64_t chain, uint32_t step)
+{
+    int d = m->theta_dim, yd = m->y_dim;
+    float thf[GLABC_MAX_DIM];
+    if (!(s->flags & GLABC_FLAG_HAS_GRAD)) {                                            /* :183-184 */
+        for (int j = 0; j < d; ++j) thf[j] = (float)s->theta[j];
+        numerical_gradient(m, p, thf, seed, chain, step, 0, s->grad);
+        s->flags |= GLABC_FLAG_HAS_GRAD;
+    }
+    /* Local_proposal_forward, :25-44: z ~ DiagGaussian(d, [0.0], [0.0]); x = z*tau + theta + grad*tau**2/2 */
+    float z[GLABC_MAX_DIM], t[GLABC_MAX_DIM];
+    double x[GLABC_MAX_DIM];
+    const float tauf = (float)p->tau;
+    for (int j = 0; j < d; ++j) {
+        z[j] = 0.0f + 1.0f * dr->z[0][j];                                               /* distribution.py:170 */
+        t[j] = 0.0f + 0.5f * (dr->z[0][j] * dr->z[0][j]);                               /* :172 */
+    }
+    float log_pro = (float)(-0.5 * (double)d * GLABC_LOG_2PI) - aten_rowsum_f32(t, d);       /* distribution.py:171 */
+    for (int j = 0; j < d; ++j) {
+        float a = z[j] * tauf;
+        double b = (s->flags & GLABC_FLAG_TH64) ? ((double)a + s->theta[j]) : (double)(a + (float)s->theta[j]);
+        x[j] = b + (s->grad[j] * p->tau_sq) / 2.0;                                      /* :43 */
+    }
+    double gprop[GLABC_MAX_DIM];
+    for (int j = 0; j < d; ++j) thf[j] = (float)x[j];                                   /* :62 */
+    numerical_gradient(m, p, thf, seed, chain, step, 1, gprop);                         /* :187 */
+    /* y = generate_samples(Theta_prop, 1)[0,], :188-189: |x| (float64) + float32 noise */
+    double y[GLABC_MAX_DIM];
+    for (int j = 0; j < yd; ++j) {
+        float noise = m->noise.p0[j] + m->noise.p2[j] * dr->z[0][d + j];
+        y[j] = fabs(x[j]) + (double)noise;
+    }
+    /* log_proposal(Theta_prop, grad_prop, Theta_old, tau), :97-116 */
+    double tq[GLABC_MAX_DIM];
+    for (int j = 0; j < d; ++j) {
+        double arg = ((s->theta[j] - x[j]) - (gprop[j] * p->tau_sq) / 2.0) / p->tau;
+        double e = (arg - 0.0) / 1.0;
+        tq[j] = 0.0 + 0.5 * (e * e);
+    }
+    double lq_rev = (-0.5 * (double)d * GLABC_LOG_2PI) - aten_rowsum_f64(tq, d);
+    double log_acc = dist_log_prob_f64(&m->prior, x) + model_log_kernel_f64(m, y);     /* :190 */
+    log_acc = log_acc + lq_rev;                                                         /* :191 */
+    log_acc = log_acc - state_prior(m, s);                                              /* :192 */
+    log_acc = log_acc - state_kernel(m, s);
+    log_acc = log_acc - (double)log_pro;                                                /* :193 */
+    double log_u = (double)glabc_logf(dr->u_accept);                                    /* :194 */
+    if (log_u < log_acc) {                                                              /* :195-199 */
+        for (int j = 0; j < d; ++j) s->theta[j] = x[j];
+        for (int j = 0; j < yd; ++j) s->y[j] = y[j];
+        for (int j = 0; j < d; ++j) s->grad[j] = gprop[j];
+        s->flags |= GLABC_FLAG_TH64;
+        return 1;                                      /* NB: `local` is NOT set (GLMALA.py:195-199 vs GLMCMC.py:100) */
+    }
+    return 0;
+}
+
+/* the iSIR global move of GLMALA.py:151-180: GLMCMC's, except that the current state's slot and
+ * the weights take the dtypes described at GLABC_FLAG_TH64 / GLABC_FLAG_LW64 */
+static int mala_isir_move(const glabc_model* m, const glabc_dist* imp, int N, mala_state* s, const step_draws* dr)
+{
+    int d = m->theta_dim, yd = m->y_dim;
+    float th[GLABC_MAX_BATCH][GLABC_MAX_DIM], y[GLABC_MAX_BATCH][GLABC_MAX_DIM], lw0[GLABC_MAX_BATCH];
+    if (s->flags & GLABC_FLAG_LOCAL) {                                                  /* :152-156 */
+        if (s->flags & GLABC_FLAG_TH64) {
+            s->log_w = (state_prior(m, s) + state_kernel(m, s)) - dist_log_prob_f64(imp, s->theta);
+            s->flags |= GLABC_FLAG_LW64;
+        } else {
+            float thf[GLABC_MAX_DIM], q = 0.0f;
+            for (int j = 0; j < d; ++j) thf[j] = (float)s->theta[j];
+            dist_log_prob(imp, thf, &q);
+            s->log_w = (double)(((float)state_prior(m, s) + (float)state_kernel(m, s)) - q);
+        }
+    }
+    s->flags &= ~GLABC_FLAG_LOCAL;                                                      /* :157 */
+    for (int j = 0; j < N; ++j) {
+        float lq;
+        prop_forward(imp, dr->z[j], th[j], &lq);                                        /* :158 */
+        model_simulate(m, th[j], dr->z[j] + d, y[j]);                                   /* :163 */
+        lw0[j] = (model_prior(m, th[j]) + model_log_kernel(m, y[j])) - lq;              /* :164-165 */
+    }
+    int ind = -1;
+    if (s->flags & GLABC_FLAG_LW64) {                                                   /* float64 weights */
+        double w[GLABC_MAX_BATCH + 1];
+        w[0] = glabc_exp(s->log_w);
+        for (int j = 0; j < N; ++j) w[j + 1] = glabc_exp((double)lw0[j]);               /* :169 */
+        for (int k = 0; k <= N; ++k)
+            if (isnan(w[k])) w[k] = 0.0;                                                /* :171-172 */
+        double tot = aten_rowsum_f64(w, N + 1);                                         /* :173 */
+        double acc = 0.0;
+        for (int k = 0; k <= N; ++k) {
+            acc += w[k] / tot;
+            if (dr->u_resample < acc) { ind = k; break; }                               /* :174 */
+        }
+    } else {
+        float w[GLABC_MAX_BATCH + 1];
+        w[0] = glabc_expf((float)s->log_w);
+        for (int j = 0; j < N; ++j) w[j + 1] = glabc_expf(lw0[j]);
+        for (int k = 0; k <= N; ++k)
+            if (isnan(w[k])) w[k] = 0.0f;
+        float tot = aten_rowsum_f32(w, N + 1);
+        double acc = 0.0;
+        for (int k = 0; k <= N; ++k) {
+            acc += (double)(w[k] / tot);
+            if (dr->u_resample < acc) { ind = k; break; }
+        }
+    }
+    if (ind > 0) {                                                                      /* :175-179 */
+        for (int j = 0; j < d; ++j) s->theta[j] = (double)th[ind - 1][j];
+        for (int j = 0; j < yd; ++j) s->y[j] = (double)y[ind - 1][j];
+        s->log_w = (double)lw0[ind - 1];
+        return 1;
+    }
+    return 0;
+}
+
+static int mala_check(const glabc_model* m, const glabc_dist* imp, const glabc_mala* p, const glabc_chains* c,
+                      const glabc_run* r)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    if (!imp || !p || !c || !r) return GLABC_ERR_NULL;
+    if (!c->theta || !c->y || !c->flags || !c->theta64 || !c->y64 || !c->log_w64 || !c->grad) return GLABC_ERR_NULL;
+    if (imp->dim != m->theta_dim) return GLABC_ERR_DIM;
+    if (c->n_chains < 0 || c->stride < c->n_chains || r->n_steps < 0) return GLABC_ERR_ARG;
+    if (r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH) return GLABC_ERR_ARG;
+    if (p->num_grad < 2 || !(p->tau > 0.0)) return GLABC_ERR_ARG;
+    if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
+    if (r->tape) return GLABC_ERR_ARG;
+    return 0;
+}
+
+ORACLE_API int oracle_glmala_init(const glabc_model* m, const glabc_chains* c)
+{
+    if (!m || !c || !c->theta || !c->y || !c->flags || !c->theta64 || !c->y64 || !c->log_w64 || !c->grad)
+        return GLABC_ERR_NULL;
+    for (int64_t i = 0; i < c->n_chains; ++i) {
+        for (int j = 0; j < m->theta_dim; ++j) {
+            c->theta64[j * c->stride + i] = (double)c->theta[j * c->stride + i];
+            c->grad[j * c->stride + i] = 0.0;
+        }
+        for (int j = 0; j < m->y_dim; ++j) c->y64[j * c->stride + i] = (double)c->y[j * c->stride + i];
+        c->log_w64[i] = 0.0;
+        c->flags[i] = GLABC_FLAG_LOCAL;                                                 /* GLMALA.py:146-147 */
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_glmala_steps(const glabc_model* m, const glabc_dist* imp, const glabc_mala* p,
+                                   const glabc_chains* c, const glabc_run* run)
+{
+    int rc = mala_check(m, imp, p, c, run);
+    if (rc) return rc;
+    int N = run->batch_size, d = m->theta_dim, yd = m->y_dim;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < c->n_chains; ++i) {
+        mala_state s;
+        step_draws dr;
+        memset(&dr, 0, sizeof dr);
+        for (int j = 0; j < d; ++j) {
+            s.theta[j] = c->theta64[j * c->stride + i];
+            s.grad[j] = c->grad[j * c->stride + i];
+        }
+        for (int j = 0; j < yd; ++j) s.y[j] = c->y64[j * c->stride + i];
+        s.log_w = c->log_w64[i];
+        s.flags = c->flags[i];
+        s.n_moves = c->n_moves ? c->n_moves[i] : 0u;
+        const uint64_t chain = (uint64_t)(c->chain0 + i);
+        for (int64_t t = 0; t < run->n_steps; ++t) {
+            const uint32_t step = run->step0 + (uint32_t)t;
+            float prev[GLABC_MAX_DIM], cur[GLABC_MAX_DIM];
+            for (int j = 0; j < d; ++j) prev[j] = (float)s.theta[j];
+            draws_from_philox(&dr, run->seed, chain, step, N, d, yd, 0);
+            if (dr.u_branch < run->global_frequency) {                                  /* GLMALA.py:151 */
+                if (imp->kind == GLABC_DIST_UNIFORM) draws_from_philox(&dr, run->seed, chain, step, N, d, yd, 1);
+                s.n_moves += (uint32_t)mala_isir_move(m, imp, N, &s, &dr);
+            } else {
+                s.n_moves += (uint32_t)mala_move(m, p, &s, &dr, run->seed, chain, step);
+            }
+            for (int j = 0; j < d; ++j) cur[j] = (float)s.theta[j];                     /* Theta_Re is float32, :148,180,200 */
+            record(run, c, i, t, d, cur, prev);
+        }
+        for (int j = 0; j < d; ++j) {
+            c->theta64[j * c->stride + i] = s.theta[j];
+            c->grad[j * c->stride + i] = s.grad[j];
+            c->theta[j * c->stride + i] = (float)s.theta[j];
+        }
+        for (int j = 0; j < yd; ++j) {
+            c->y64[j * c->stride + i] = s.y[j];
+            c->y[j * c->stride + i] = (float)s.y[j];
+        }
+        c->log_w64[i] = s.log_w;
+        if (c->log_w) c->log_w[i] = (float)s.log_w;
+        c->flags[i] = s.flags;
+        if (c->n_moves) c->n_moves[i] = s.n_moves;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* ESJD.py:2-25 : det( D^T D / (n-1) )^(1/d), D = consecutive differences, all float32.
  * torch.det is an LU with partial pivoting; restated for d <= GLABC_MAX_DIM.
@@ -645,6 +1024,16 @@ ORACLE_API void oracle_uniforms_v(const uint32_t* a, const uint32_t* b, int64_t 
         upos[i] = glabc_uniform_pos_f32(a[i]);
         u64[i] = glabc_uniform_f64(a[i], b[i]);
     }
+}
+
+ORACLE_API void oracle_exp_v(const double* x, int64_t n, double* out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = glabc_exp(x[i]);
+}
+
+ORACLE_API void oracle_log_v(const double* x, int64_t n, double* out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = glabc_log(x[i]);
 }
 
 /* the draws of one (chain, step) exactly as the samplers consume them */

@@ -44,6 +44,7 @@ sys.path.insert(0, os.path.join(REF, "glabcmcmc", "examples"))
 import glabcmcmc.distribution as rdist          # noqa: E402
 import glabcmcmc.GLMCMC as rglmcmc              # noqa: E402
 import glabcmcmc.GlobalMCMC as rglobal          # noqa: E402
+import glabcmcmc.GLMALA as rglmala              # noqa: E402
 import glabcmcmc.ESJD as resjd                  # noqa: E402
 from Mixture import Mixture_set                 # noqa: E402
 
@@ -56,11 +57,31 @@ torch.set_num_threads(1)
 class Tape:
     """Numbers for one chain: u[T,2] (branch, accept), r[T] f64, z[T,P,d+yd]."""
 
-    def __init__(self, u, r, z, d, gf, isir):
+    def __init__(self, u, r, z, d, gf, isir, grad_fn=None):
         self.u, self.r, self.z, self.d, self.gf, self.isir = u, r, z, d, gf, isir
         self.t = -1
         self.expect = "branch"
         self.k = 0
+        # GLMALA: numberical_gradient_logABC reseeds torch before each block of simulations
+        # (GLMALA.py:76,80); the patched manual_seed marks the next randn as gradient noise of
+        # (g, coordinate): g = 0 gradient at Theta_old (first local move only), g = 1 at the proposal
+        self.grad_fn = grad_fn
+        self.grad_done = False
+        self.ms_count = 0
+        self.ms_init = False
+        self.pending = None
+
+    def manual_seed(self, seed):
+        if self.ms_count == 0:
+            self.ms_init = not self.grad_done
+        idx = self.ms_count // 2
+        self.ms_count += 1
+        if self.ms_init:
+            g, k = (0, idx) if idx < self.d else (1, idx - self.d)
+        else:
+            g, k = 1, idx
+        self.pending = (g, k)
+        self.grad_done = True
 
     def rand(self, *size, **kw):
         if len(size) == 1 and isinstance(size[0], (tuple, list)):
@@ -71,6 +92,7 @@ class Tape:
         if self.expect == "branch":
             self.t += 1
             self.k = 0
+            self.ms_count = 0
             v = self.u[self.t, 0]
             if not (self.isir and v < self.gf):
                 self.expect = "accept"
@@ -80,6 +102,12 @@ class Tape:
         return torch.tensor([v], dtype=torch.float32)
 
     def _noise(self, shape):
+        if self.pending is not None:
+            g, k = self.pending
+            self.pending = None
+            out = self.grad_fn(self.t, g, k)
+            assert tuple(shape) == out.shape, (shape, out.shape)
+            return torch.from_numpy(out)
         n, dd = shape
         lo = 0 if self.k == 0 else self.d
         out = self.z[self.t, :n, lo:lo + dd]
@@ -95,15 +123,27 @@ class Tape:
         return float(self.r[self.t])
 
 
+def _ieee_sqrt(t):
+    """correctly rounded square root (NumPy's) in place of torch.sqrt: this torch build's CPU sqrt goes
+    through MKL VML 'high accuracy' mode, which is 1 ulp low for 0.65 % of float32 inputs"""
+    return torch.from_numpy(np.sqrt(t.detach().numpy()))
+
+
 @contextlib.contextmanager
-def patched(tape):
-    saved = (torch.rand, torch.randn, np.random.uniform)
+def patched(tape, ieee_sqrt=False):
+    import secrets
+    saved = (torch.rand, torch.randn, np.random.uniform, torch.manual_seed, np.random.seed, secrets.randbelow,
+             torch.sqrt)
     torch.rand, torch.randn, np.random.uniform = tape.rand, tape.randn, tape.uniform
+    torch.manual_seed, np.random.seed, secrets.randbelow = tape.manual_seed, (lambda s: None), (lambda n: 12345)
+    if ieee_sqrt:
+        torch.sqrt = _ieee_sqrt
     try:
         with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
             yield
     finally:
-        torch.rand, torch.randn, np.random.uniform = saved
+        (torch.rand, torch.randn, np.random.uniform, torch.manual_seed, np.random.seed, secrets.randbelow,
+         torch.sqrt) = saved
 
 
 def make_dist(spec):
@@ -161,9 +201,11 @@ def run_reference(algo, cfg, theta0, y0, tape):
     T = cfg["T"]
     th0 = torch.from_numpy(theta0.copy())
     yy0 = torch.from_numpy(y0.copy()).view(1, -1)
-    with patched(tape):
+    with patched(tape, cfg.get("ieee_sqrt", False)):
         if algo == "glmcmc":
             out = rglmcmc.GLMCMC(model, T + 1, th0, yy0, local, None, cfg["gf"], glob, cfg["N"])
+        elif algo == "glmala":
+            out = rglmala.GLMALA(model, T + 1, th0, yy0, cfg["tau"], cfg["num_grad"], None, cfg["gf"], glob, cfg["N"])
         else:
             out = rglobal.GlobalMCMC(model, T + 1, th0, yy0, glob, None, cfg["gf"], local)
     assert tape.t == T - 1, (tape.t, T)
@@ -174,7 +216,7 @@ def sampler_fixture(name, algo, cfg, mode):
     L = oracle_lib.load()
     d = yd = 2
     C, T, N = cfg["C"], cfg["T"], cfg["N"]
-    P = N if algo == "glmcmc" else 1
+    P = N if algo in ("glmcmc", "glmala") else 1
     rng = np.random.default_rng(cfg["seed"] + 1000)
     theta0 = (rng.standard_normal((C, d)) * cfg.get("theta0_sd", 0.0)).astype(np.float32)
     y0 = (np.abs(theta0) + np.sqrt(np.float32(0.05)) * rng.standard_normal((C, yd)).astype(np.float32)).astype(np.float32)
@@ -189,7 +231,15 @@ def sampler_fixture(name, algo, cfg, mode):
             assert ug == ul
             u, r, z = numpy_tape(rng, T, P, d, yd, ug)
             tapes.append((u, r, z))
-        tape = Tape(u, r, z, d, np.float32(cfg["gf"]), algo == "glmcmc")
+        grad_fn = None
+        if algo == "glmala":
+            num, chain_id = cfg["num_grad"], cfg.get("chain0", 0) + c
+
+            def grad_fn(t, g, k, num=num, chain_id=chain_id):
+                out = np.zeros((num, yd), np.float32)
+                L.oracle_grad_noise(cfg["seed"], chain_id, t + 1, g, k, num, yd, out.ctypes.data)
+                return out
+        tape = Tape(u, r, z, d, np.float32(cfg["gf"]), algo in ("glmcmc", "glmala"), grad_fn)
         chains[:, c, :] = run_reference(algo, cfg, theta0[c], y0[c], tape)
         print("\r%s chain %d/%d" % (name, c + 1, C), end="", flush=True)
     print()
@@ -227,6 +277,29 @@ SAMPLER_FIXTURES = {
                                                    local=G2(0.35), **{"global": G2(1.0)}), "philox"),
     "globalmcmc_philox_wide": ("globalmcmc", dict(epsilon=0.3, gf=0.5, N=1, C=16, T=600, seed=12, theta0_sd=1.0,
                                                   local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    # BASELINE config 3's algorithm and parameters (README.md:128: gf 0.8, N 5, tau 0.3, num_grad 100)
+    "glmala_philox_bench": ("glmala", dict(epsilon=0.05, gf=0.8, N=5, tau=0.3, num_grad=100, C=24, T=500, seed=31,
+                                           local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    # mostly local moves, wide kernel: many accepted MALA moves -> float64 state, stale weights
+    "glmala_philox_local": ("glmala", dict(epsilon=0.3, gf=0.3, N=3, tau=0.25, num_grad=10, C=16, T=300, seed=32,
+                                           theta0_sd=1.0, local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    "glmala_philox_alllocal": ("glmala", dict(epsilon=0.3, gf=0.0, N=2, tau=0.2, num_grad=7, C=8, T=200, seed=33,
+                                              theta0_sd=1.0, local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    "glmala_philox_allglobal": ("glmala", dict(epsilon=0.3, gf=1.0, N=4, tau=0.3, num_grad=5, C=8, T=200, seed=34,
+                                               theta0_sd=1.0, local=G2(0.35), **{"global": ("gauss", [0.2, -0.1], [1.2, 0.9])}), "philox"),
+    # the same two configurations with torch.sqrt replaced by a correctly rounded sqrt for the run: GLMALA's
+    # chains depend on the last bit of every simulated discrepancy (the float32 finite-difference prior
+    # gradient, GLMALA.py:84-85, turns a 1-ulp change of theta into a 1e-2 change of the drift), and this
+    # torch build's sqrt (MKL VML) is not correctly rounded -- see DESIGN.md
+    "glmala_philox_bench_ieee": ("glmala", dict(epsilon=0.05, gf=0.8, N=5, tau=0.3, num_grad=100, C=24, T=500, seed=31,
+                                                ieee_sqrt=True, local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    "glmala_philox_local_ieee": ("glmala", dict(epsilon=0.3, gf=0.3, N=3, tau=0.25, num_grad=10, C=16, T=300, seed=32,
+                                                ieee_sqrt=True, theta0_sd=1.0, local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    "glmala_philox_uniform_ieee": ("glmala", dict(epsilon=0.3, gf=0.5, N=4, tau=0.3, num_grad=12, C=8, T=300, seed=35,
+                                                  ieee_sqrt=True, theta0_sd=1.0, local=G2(0.35),
+                                                  **{"global": ("uniform", [-3.0, -3.0], [3.0, 3.0])}), "philox"),
+    "glmala_philox_uniform": ("glmala", dict(epsilon=0.3, gf=0.5, N=4, tau=0.3, num_grad=12, C=8, T=300, seed=35,
+                                             theta0_sd=1.0, local=G2(0.35), **{"global": ("uniform", [-3.0, -3.0], [3.0, 3.0])}), "philox"),
     # stored-tape fixtures (NumPy numbers; independent of the Philox specification)
     "glmcmc_tape_small": ("glmcmc", dict(epsilon=0.2, gf=0.8, N=5, C=8, T=300, seed=21, theta0_sd=1.0,
                                          local=G2(0.35), **{"global": G2(1.0)}), "tape"),
@@ -341,10 +414,47 @@ def primitives():
     print("primitives: %d arrays" % len(out))
 
 
+def gradient_fixture():
+    """numberical_gradient_logABC (GLMALA.py:46-95) on a grid of thetas, noise from the Philox gradient slots,
+    torch.sqrt correctly rounded (see _ieee_sqrt)."""
+    import secrets
+    L = oracle_lib.load()
+    cfg = dict(epsilon=0.05, tau=0.3, num_grad=100, seed=41, local=G2(0.35), **{"global": G2(1.0)})
+    rng = np.random.default_rng(41)
+    n = 64
+    theta = (rng.standard_normal((n, 2)) * 1.5).astype(np.float32)
+    chain = rng.integers(0, 1 << 40, n)
+    step = rng.integers(1, 1 << 20, n)
+    grads = np.zeros((n, 2))
+    model = Mixture_set(cfg["epsilon"])
+    for i in range(n):
+        noise = [np.zeros((cfg["num_grad"], 2), np.float32) for _ in range(2)]
+        for k in range(2):
+            L.oracle_grad_noise(cfg["seed"], int(chain[i]), int(step[i]), 1, k, cfg["num_grad"], 2, noise[k].ctypes.data)
+        calls = [0]
+
+        def randn(*a, **kw):
+            k = calls[0] // 2
+            calls[0] += 1
+            return torch.from_numpy(noise[k])
+        saved = (torch.manual_seed, torch.randn, np.random.seed, secrets.randbelow, torch.sqrt)
+        torch.manual_seed, torch.randn, np.random.seed, secrets.randbelow, torch.sqrt = \
+            (lambda s: None), randn, (lambda s: None), (lambda m: 7), _ieee_sqrt
+        try:
+            grads[i] = rglmala.numberical_gradient_logABC(model, torch.from_numpy(theta[i]), cfg["num_grad"]).numpy().ravel()
+        finally:
+            torch.manual_seed, torch.randn, np.random.seed, secrets.randbelow, torch.sqrt = saved
+    np.savez_compressed(os.path.join(HERE, "glmala_gradient.npz"), theta=theta, chain=chain, step=step, grad=grads,
+                        cfg=np.array(repr(cfg)))
+    print("glmala_gradient: %d points" % n)
+
+
 if __name__ == "__main__":
     want = sys.argv[1:]
     if not want or "primitives" in want:
         primitives()
+    if not want or "glmala_gradient" in want:
+        gradient_fixture()
     for name, (algo, cfg, mode) in SAMPLER_FIXTURES.items():
         if not want or name in want or algo in want:
             sampler_fixture(name, algo, cfg, mode)

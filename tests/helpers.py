@@ -41,6 +41,20 @@ SAMPLER_GOLDENS = [
     "glmcmc_tape_small", "globalmcmc_tape_small",
 ]
 
+# reference run with a correctly rounded torch.sqrt (see make_golden.py): bit parity expected
+GLMALA_GOLDENS_EXACT = ["glmala_philox_bench_ieee", "glmala_philox_local_ieee", "glmala_philox_uniform_ieee",
+                        "glmala_philox_allglobal"]
+# reference run as-is (torch.sqrt = MKL VML, 1 ulp low for 0.65 % of float32 inputs): parity until the
+# first sqrt-ulp event of a chain, which the float32 finite-difference prior gradient then amplifies
+GLMALA_GOLDENS_MKL = ["glmala_philox_bench", "glmala_philox_local", "glmala_philox_alllocal", "glmala_philox_uniform"]
+GLMALA_GOLDENS = GLMALA_GOLDENS_EXACT + GLMALA_GOLDENS_MKL
+
+
+def mala_params(cfg):
+    """glabc_mala with tau**2 and epsilon**2 evaluated in Python floats, as GLMALA.py:43,90 do"""
+    from glabcmcmc_amd import _capi as A
+    return A.Mala(float(cfg["tau"]), float(cfg["tau"]) ** 2, float(cfg["epsilon"]) ** 2, int(cfg["num_grad"]), 0)
+
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)

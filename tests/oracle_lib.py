@@ -28,6 +28,14 @@ _SIG = {
     "oracle_init_weights": (C.c_int, [_P(A.Model), _P(A.Dist), _P(A.Chains)]),
     "oracle_glmcmc_steps": (C.c_int, [_P(A.Model), _P(A.Dist), _P(A.Dist), _P(A.Chains), _P(A.Run)]),
     "oracle_globalmcmc_steps": (C.c_int, [_P(A.Model), _P(A.Dist), _P(A.Dist), _P(A.Chains), _P(A.Run)]),
+    "oracle_aten_rowsum_f64": (C.c_double, [C.c_void_p, C.c_int]),
+    "oracle_grad_noise": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "oracle_numerical_gradient": (C.c_int, [_P(A.Model), _P(A.Mala), C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
+                                            C.c_int, C.c_void_p]),
+    "oracle_glmala_init": (C.c_int, [_P(A.Model), _P(A.Chains)]),
+    "oracle_glmala_steps": (C.c_int, [_P(A.Model), _P(A.Dist), _P(A.Mala), _P(A.Chains), _P(A.Run)]),
+    "oracle_exp_v": (None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "oracle_log_v": (None, [C.c_void_p, C.c_int64, C.c_void_p]),
     "oracle_esjd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "oracle_philox4x32_10": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "oracle_expf_v": (None, [C.c_void_p, C.c_int64, C.c_void_p]),
@@ -81,7 +89,17 @@ class HostChains:
 
     def struct(self):
         return A.Chains(self.n, self.chain0, self.n, ptr(self.theta), ptr(self.y), ptr(self.log_w),
-                        ptr(self.flags), ptr(self.n_moves))
+                        ptr(self.flags), ptr(self.n_moves), ptr(getattr(self, "theta64", None)),
+                        ptr(getattr(self, "y64", None)), ptr(getattr(self, "log_w64", None)),
+                        ptr(getattr(self, "grad", None)))
+
+    def add_mala_state(self):
+        """the float64 state arrays of GLMALA (glabc_chains.theta64 ...)"""
+        self.theta64 = np.zeros_like(self.theta, dtype=np.float64)
+        self.y64 = np.zeros_like(self.y, dtype=np.float64)
+        self.log_w64 = np.zeros(self.n, np.float64)
+        self.grad = np.zeros_like(self.theta, dtype=np.float64)
+        return self
 
 
 class HostMoments:

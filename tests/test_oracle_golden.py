@@ -7,7 +7,7 @@ import pytest
 
 import oracle_lib
 from glabcmcmc_amd import _capi as A
-from helpers import SAMPLER_GOLDENS, bits, descriptors, load_golden
+from helpers import GLMALA_GOLDENS_EXACT, GLMALA_GOLDENS_MKL, SAMPLER_GOLDENS, bits, descriptors, load_golden, mala_params
 
 # The oracle's exp/log are those of include/glabc_numerics.h, ATen's are its own vectorised
 # ones; densities agree to a few float32 ulp of the largest term, not bit for bit.
@@ -163,3 +163,86 @@ def test_sampler_chains_bit_exact(oracle, name):
     moves = (np.diff(ref, axis=0) != 0).any(-1).sum(0)
     assert np.array_equal(ch.n_moves, moves.astype(np.uint32))
     assert moves.sum() > 0
+
+
+def run_oracle_glmala(oracle, g):
+    cfg = g["cfg"]
+    model, _, glob = descriptors(cfg)
+    mala = mala_params(cfg)
+    C_, T, d = g["theta0"].shape[0], cfg["T"], 2
+    ch = oracle_lib.HostChains(g["theta0"], g["y0"], chain0=cfg.get("chain0", 0)).add_mala_state()
+    hist = np.zeros((T, d, C_), np.float32)
+    run, keep = oracle_lib.make_run(seed=cfg["seed"], step0=1, n_steps=T, gf=cfg["gf"], batch=cfg["N"], history=hist)
+    cs = ch.struct()
+    assert oracle.oracle_glmala_init(C.byref(model), C.byref(cs)) == 0
+    assert oracle.oracle_glmala_steps(C.byref(model), C.byref(glob), C.byref(mala), C.byref(cs), C.byref(run)) == 0
+    chains = np.concatenate([g["theta0"][None], hist.transpose(0, 2, 1)], axis=0)
+    return chains, ch
+
+
+@pytest.mark.parametrize("name", GLMALA_GOLDENS_EXACT)
+def test_glmala_chains_bit_exact(oracle, name):
+    """GLMALA.py:150-200 (iSIR + MALA with the common-random-number finite-difference gradient, the
+    float32 -> float64 switch of the state, the stale iSIR weight) replayed on the same random
+    numbers, with the reference's torch.sqrt correctly rounded: every recorded float32 Theta_Re row
+    of every chain equals the reference's."""
+    g = load_golden(name)
+    chains, ch = run_oracle_glmala(oracle, g)
+    ref = g["chains"]
+    same = bits(chains) == bits(ref)
+    assert same.all(), "first mismatch at (t, chain, dim) = %s of %d" % (np.argwhere(~same)[0], (~same).sum())
+    moves = (np.diff(ref, axis=0) != 0).any(-1).sum(0)
+    assert np.array_equal(ch.n_moves, moves.astype(np.uint32))
+    if g["cfg"]["gf"] < 1.0:
+        assert (ch.flags & A.FLAG_TH64).any()          # some chain really switched to float64
+
+
+def divergence_profile(chains, ref):
+    """per chain: index of the first differing row (T+1 if none) and the size of that first difference in ulp"""
+    same = (bits(chains) == bits(ref)).all(-1)
+    Tn, Cn = same.shape
+    first = np.where(same.all(0), Tn, np.argmin(same, axis=0))
+    ulp = np.zeros(Cn)
+    for c in range(Cn):
+        if first[c] < Tn:
+            a, b = chains[first[c], c].astype(np.float64), ref[first[c], c].astype(np.float64)
+            ulp[c] = (np.abs(a - b) / np.spacing(np.abs(ref[first[c], c])).astype(np.float64)).max()
+    return first, ulp
+
+
+@pytest.mark.parametrize("name", GLMALA_GOLDENS_MKL)
+def test_glmala_vs_unpatched_reference(oracle, name):
+    """Against the reference exactly as it runs on this torch build (MKL VML sqrt, not correctly
+    rounded): a chain follows the reference bit for bit until its first sqrt-ulp event; that first
+    difference is a few float32 ulp, i.e. ~1e-6 relative (afterwards the float32 finite-difference prior gradient,
+    GLMALA.py:84-85, amplifies it and the trajectories separate), and the number of accepted moves
+    stays within 1 %."""
+    g = load_golden(name)
+    chains, ch = run_oracle_glmala(oracle, g)
+    ref = g["chains"]
+    first, ulp = divergence_profile(chains, ref)
+    Tn = ref.shape[0]
+    assert (first >= 1).all()
+    assert ulp.max() <= 16.0 and np.median(ulp[ulp > 0]) <= 2.0, ulp
+    if name == "glmala_philox_bench":                   # BASELINE config 3: few accepted MALA moves per chain
+        assert (first == Tn).mean() >= 0.75
+    moves_ref = (np.diff(ref, axis=0) != 0).any(-1).sum()
+    assert abs(int(ch.n_moves.sum()) - int(moves_ref)) <= 0.01 * moves_ref + 1
+
+
+def test_glmala_gradient_matches_reference(oracle):
+    """numberical_gradient_logABC (GLMALA.py:46-95) on golden inputs: reference values were produced with
+    the correctly rounded sqrt; the float64 result agrees to ~1e-13 (torch.mean / torch.var / torch.log use
+    their own summation cascades and MKL's log)."""
+    g = load_golden("glmala_gradient")
+    cfg = g["cfg"]
+    model, _, _ = descriptors(cfg)
+    mala = mala_params(cfg)
+    out = np.zeros(2)
+    worst = 0.0
+    for i in range(g["theta"].shape[0]):
+        th = np.ascontiguousarray(g["theta"][i])
+        assert oracle.oracle_numerical_gradient(C.byref(model), C.byref(mala), th.ctypes.data, cfg["seed"], int(g["chain"][i]),
+                                                int(g["step"][i]), 1, out.ctypes.data) == 0
+        worst = max(worst, np.max(np.abs(out - g["grad"][i]) / np.maximum(1.0, np.abs(g["grad"][i]))))
+    assert worst < 1e-11, worst
