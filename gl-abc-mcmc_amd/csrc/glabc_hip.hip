@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 
+#include "glabc_mala.h"
 #include "glabc_sampler.h"
 
 namespace glabc {
@@ -399,6 +400,90 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
     if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
     return rc;
 }
+
+template <int D>
+static MalaArgs<D> pack_mala(const glabc_model* m, const glabc_dist* imp, const glabc_mala* p, const glabc_chains* c,
+                             const glabc_run* r)
+{
+    MalaArgs<D> a;
+    std::memset(&a, 0, sizeof a);
+    a.s = pack_args<D>(m, nullptr, imp ? imp : &m->prior, c, r);
+    a.theta64 = c->theta64;
+    a.y64 = c->y64;
+    a.log_w64 = c->log_w64;
+    a.grad = c->grad;
+    if (p) {
+        a.tau = p->tau;
+        a.tau_sq = p->tau_sq;
+        a.eps_sq = p->eps_sq;
+        a.num_grad = p->num_grad;
+    }
+    return a;
+}
+
+static int check_mala_chains(const glabc_chains* c)
+{
+    if (!c) return GLABC_ERR_NULL;
+    if (!c->theta || !c->y || !c->flags || !c->theta64 || !c->y64 || !c->log_w64 || !c->grad) return GLABC_ERR_NULL;
+    if (c->n_chains < 0 || c->stride < c->n_chains || c->chain0 < 0) return GLABC_ERR_ARG;
+    return GLABC_OK;
+}
+
+extern "C" {
+
+__attribute__((visibility("default"))) int glabc_glmala_steps(const glabc_model* model, const glabc_dist* importance,
+                                                              const glabc_mala* mala, const glabc_chains* c,
+                                                              const glabc_run* r, void* stream)
+{
+    int rc = check_model(model);
+    if (rc) return rc;
+    rc = check_dist(importance, model->theta_dim);
+    if (rc) return rc;
+    if (!mala || !r) return GLABC_ERR_NULL;
+    rc = check_mala_chains(c);
+    if (rc) return rc;
+    if (r->n_steps < 0 || r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH) return GLABC_ERR_ARG;
+    if (!(r->global_frequency >= 0.0f) && !(r->global_frequency < 0.0f)) return GLABC_ERR_ARG;
+    if (mala->num_grad < 2 || mala->num_grad > (1 << 16) || !(mala->tau > 0.0) || !std::isfinite(mala->tau) ||
+        !std::isfinite(mala->tau_sq) || !std::isfinite(mala->eps_sq) || !(mala->eps_sq >= 0.0))
+        return GLABC_ERR_ARG;
+    if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
+    if (r->moments && (!r->moments->sum_theta || !r->moments->sum_outer || !r->moments->sum_jump)) return GLABC_ERR_NULL;
+    if (r->tape) return GLABC_ERR_ARG;
+    if ((uint64_t)r->step0 + (uint64_t)r->n_steps > 0xFFFFFFFFull) return GLABC_ERR_ARG;
+    if (c->n_chains == 0 || r->n_steps == 0) return GLABC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    switch (model->theta_dim) {
+    case 1: rc = launch_glmala_dim<1>(r->batch_size, pack_mala<1>(model, importance, mala, c, r), s); break;
+    case 2: rc = launch_glmala_dim<2>(r->batch_size, pack_mala<2>(model, importance, mala, c, r), s); break;
+    case 3: rc = launch_glmala_dim<3>(r->batch_size, pack_mala<3>(model, importance, mala, c, r), s); break;
+    case 4: rc = launch_glmala_dim<4>(r->batch_size, pack_mala<4>(model, importance, mala, c, r), s); break;
+    default: return GLABC_ERR_DIM;
+    }
+    if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
+    return rc;
+}
+
+__attribute__((visibility("default"))) int glabc_glmala_init(const glabc_model* model, const glabc_chains* c, void* stream)
+{
+    int rc = check_model(model);
+    if (rc) return rc;
+    rc = check_mala_chains(c);
+    if (rc) return rc;
+    if (c->n_chains == 0) return GLABC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    switch (model->theta_dim) {
+    case 1: rc = launch_glmala_init_dim<1>(pack_mala<1>(model, nullptr, nullptr, c, nullptr), s); break;
+    case 2: rc = launch_glmala_init_dim<2>(pack_mala<2>(model, nullptr, nullptr, c, nullptr), s); break;
+    case 3: rc = launch_glmala_init_dim<3>(pack_mala<3>(model, nullptr, nullptr, c, nullptr), s); break;
+    case 4: rc = launch_glmala_init_dim<4>(pack_mala<4>(model, nullptr, nullptr, c, nullptr), s); break;
+    default: return GLABC_ERR_DIM;
+    }
+    if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
+    return rc;
+}
+
+}  // extern "C"
 
 template <int OP>
 static int launch_rowwise(const RowArgs& a, hipStream_t s)

@@ -1,0 +1,513 @@
+// glabc_mala.h -- fused GLMALA step (GLMALA.py:118-230) for gfx950.
+//
+// One work-item owns one chain.  The chain's state lives in VGPRs as doubles together with the
+// two sticky precision bits of include/glabc.h (GLABC_FLAG_TH64 / GLABC_FLAG_LW64): the reference's
+// tensors change dtype while a chain runs, so every density is evaluated in the precision the
+// reference would be using at that point (float32-exact values are carried in doubles).
+//
+// The MALA drift is the reference's common-random-number central-difference gradient of a
+// synthetic-likelihood log-ABC: 2 * theta_dim * num_grad simulator calls per local move
+// (numberical_gradient_logABC, GLMALA.py:46-95), looped in-lane here.  Its noise comes from Philox
+// slots GRAD_BASE + g*GRAD_STRIDE + block (normal n = (k*num + s)*y_dim + j in block n/4), shared by
+// the +d and -d simulations of a coordinate as the reference's reseeding does (GLMALA.py:76,80).
+//
+// The operation order is the reference's, line by line (citations on the right); the CPU checker
+// restates the same lines independently in plain C and is compared bit for bit in the tests.
+#pragma once
+
+#include "glabc_device.h"
+
+namespace glabc {
+
+constexpr uint32_t GRAD_BASE = 0x100000u;
+constexpr uint32_t GRAD_STRIDE = 0x80000u;
+
+template <int D>
+struct MalaArgs {
+    StepArgs<D> s;               // model, importance proposal (s.global), chains, run
+    double* theta64;
+    double* y64;
+    double* log_w64;
+    double* grad;
+    double tau, tau_sq, eps_sq;
+    int32_t num_grad;
+};
+
+// ATen's float64 row sum: the float32 scheme of aten_rowsum with 4-wide vectors (probed)
+template <int N>
+GLABC_DEV double aten_rowsum_f64(const double (&x)[N])
+{
+    if constexpr (N < 4) {
+        double s = x[0];
+#pragma unroll
+        for (int i = 1; i < N; ++i) s = s + x[i];
+        return s;
+    } else {
+        constexpr int NV = N / 4;
+        constexpr int G = NV / 4;
+        double acc[4];
+        if constexpr (G == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[k] = x[k];
+#pragma unroll
+                for (int v = 1; v < NV; ++v) acc[k] = acc[k] + x[4 * v + k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) l[q] = x[4 * q + k];
+#pragma unroll
+                for (int i = 1; i < G; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) l[q] = l[q] + x[4 * (4 * i + q) + k];
+#pragma unroll
+                for (int v = 4 * G; v < NV; ++v) l[0] = l[0] + x[4 * v + k];
+                acc[k] = ((l[0] + l[1]) + l[2]) + l[3];
+            }
+        }
+        double fa = 0.0;
+#pragma unroll
+        for (int i = 4 * NV; i < N; ++i) fa = fa + x[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fa = fa + acc[k];
+        return fa;
+    }
+}
+
+// distribution.py:176-181 / 81-86 on a float64 tensor
+template <int D>
+GLABC_DEV double dist_log_prob_f64(const DistArgs<D>& g, const double (&z)[D])
+{
+    if (g.kind == GLABC_DIST_DIAG_GAUSS) {
+        double t[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double e = (z[j] - (double)g.p0[j]) / (double)g.p2[j];
+            t[j] = (double)g.p1[j] + 0.5 * (e * e);
+        }
+        return (-0.5 * (double)D * GLABC_LOG_2PI) - aten_rowsum_f64<D>(t);
+    }
+    bool out = false;
+#pragma unroll
+    for (int j = 0; j < D; ++j) out = out || (z[j] < (double)g.p0[j]) || (z[j] > (double)g.p1[j]);
+    return out ? -__builtin_inf() : (double)g.c0;
+}
+
+// Mixture.py:33-45 on a float64 y
+template <int D>
+GLABC_DEV double model_log_kernel_f64(const StepArgs<D>& a, const double (&y)[D])
+{
+    double t[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double d = y[j] - (double)a.y_obs[j];
+        t[j] = d * d;
+    }
+    double dis = __builtin_sqrt(aten_rowsum_f64<D>(t));
+    double e = (dis - 0.0) / (double)a.kern_scale;
+    return (-0.5 * 1.0 * GLABC_LOG_2PI) - ((double)a.kern_log_scale + 0.5 * (e * e));
+}
+
+// discrepancy, Mixture.py:33-36, float32
+template <int D>
+GLABC_DEV float model_discrepancy(const StepArgs<D>& a, const float (&y)[D])
+{
+    float t[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        float d = y[j] - a.y_obs[j];
+        t[j] = d * d;
+    }
+    return __builtin_sqrtf(aten_rowsum<D>(t));
+}
+
+template <int D>
+struct MalaChain {
+    double theta[D], y[D], grad[D];
+    double log_w;
+    uint32_t flags, n_moves;
+};
+
+template <int D>
+GLABC_DEV double state_prior(const StepArgs<D>& a, const MalaChain<D>& c)
+{
+    if (c.flags & GLABC_FLAG_TH64) return dist_log_prob_f64<D>(a.prior, c.theta);
+    float th[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) th[j] = (float)c.theta[j];
+    return (double)dist_log_prob<D>(a.prior, th);
+}
+
+template <int D>
+GLABC_DEV double state_kernel(const StepArgs<D>& a, const MalaChain<D>& c)
+{
+    if (c.flags & GLABC_FLAG_TH64) return model_log_kernel_f64<D>(a, c.y);
+    float y[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) y[j] = (float)c.y[j];
+    return (double)model_log_kernel<D>(a, y);
+}
+
+// numberical_gradient_logABC, GLMALA.py:46-95, for one float32 theta
+template <int D>
+GLABC_DEV void numerical_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step, int g, const float (&theta)[D],
+                                  double (&grad)[D])
+{
+    const StepArgs<D>& a = m.s;
+    const int num = m.num_grad;
+    const float h = 0.1f, hp = 0.00001f;
+#pragma unroll 1
+    for (int k = 0; k < D; ++k) {
+        float tp[D], tm[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            tp[j] = theta[j] + (j == k ? h : 0.0f);                  // GLMALA.py:67
+            tm[j] = theta[j] - (j == k ? h : 0.0f);                  // GLMALA.py:68
+        }
+        double c_p = 0.0, c_m = 0.0, s1p = 0.0, s2p = 0.0, s1m = 0.0, s2m = 0.0;
+        uint32_t cached_block = 0xffffffffu;
+        glabc_u32x4 blk;
+        blk.v[0] = blk.v[1] = blk.v[2] = blk.v[3] = 0u;
+#pragma unroll 1
+        for (int s = 0; s < num; ++s) {
+            float eps[D], yp[D], ym[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const int64_t n = ((int64_t)k * num + s) * D + j;
+                const uint32_t block = (uint32_t)(n >> 2);
+                if (block != cached_block) {                          // wave-uniform: every lane walks the same (k, s)
+                    blk = glabc_philox4x32_10(rng.c0, rng.c1, step, GRAD_BASE + (uint32_t)g * GRAD_STRIDE + block, rng.k0,
+                                              rng.k1);
+                    cached_block = block;
+                }
+                const int p = (int)((n & 3) >> 1);
+                float z0, z1;
+                glabc_normal_pair(p ? blk.v[2] : blk.v[0], p ? blk.v[3] : blk.v[1], &z0, &z1);
+                eps[j] = (n & 1) ? z1 : z0;
+            }
+            model_simulate<D>(a, tp, eps, yp);                        // GLMALA.py:78
+            model_simulate<D>(a, tm, eps, ym);                        // GLMALA.py:82 (same noise)
+            const double dp = (double)model_discrepancy<D>(a, yp), dm = (double)model_discrepancy<D>(a, ym);
+            if (s == 0) {
+                c_p = dp;
+                c_m = dm;
+            }
+            const double ep = dp - c_p, em = dm - c_m;
+            s1p += ep;
+            s2p += ep * ep;
+            s1m += em;
+            s2m += em * em;
+        }
+        const double n = (double)num;
+        const double mu_p = c_p + s1p / n, mu_m = c_m + s1m / n;                            // GLMALA.py:86-87
+        const double var_p = (s2p - (s1p * s1p) / n) / (n - 1.0), var_m = (s2m - (s1m * s1m) / n) / (n - 1.0);   // :88-89
+        const double lp = (-0.5 * glabc_log(var_p + m.eps_sq)) - ((0.5 * (mu_p * mu_p)) / (var_p + m.eps_sq));   // :90-91
+        const double lm = (-0.5 * glabc_log(var_m + m.eps_sq)) - ((0.5 * (mu_m * mu_m)) / (var_m + m.eps_sq));   // :92-93
+        const double gll = (lp - lm) / 0.2;                                                  // :94
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            tp[j] = theta[j] + (j == k ? hp : 0.0f);                                         // :84
+            tm[j] = theta[j] - (j == k ? hp : 0.0f);
+        }
+        const float gp = (dist_log_prob<D>(a.prior, tp) - dist_log_prob<D>(a.prior, tm)) / 0.00002f;   // :84-85
+        const double gk = gll + (double)gp;                                                  // :95
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j == k) grad[j] = gk;
+    }
+}
+
+// the MALA local move, GLMALA.py:182-200
+template <int D>
+GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, float u_accept, const float (&zn)[2 * D],
+                         MalaChain<D>& c)
+{
+    const StepArgs<D>& a = m.s;
+    float thf[D];
+    if (!(c.flags & GLABC_FLAG_HAS_GRAD)) {                                                  // :183-184
+#pragma unroll
+        for (int j = 0; j < D; ++j) thf[j] = (float)c.theta[j];
+        numerical_gradient<D>(m, rng, step, 0, thf, c.grad);
+        c.flags |= GLABC_FLAG_HAS_GRAD;
+    }
+    // Local_proposal_forward, :25-44
+    float t[D];
+    double x[D];
+    const float tauf = (float)m.tau;
+#pragma unroll
+    for (int j = 0; j < D; ++j) t[j] = 0.0f + 0.5f * (zn[j] * zn[j]);
+    const float log_pro = (float)(-0.5 * (double)D * GLABC_LOG_2PI) - aten_rowsum<D>(t);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const float z = 0.0f + 1.0f * zn[j];
+        const float av = z * tauf;
+        const double b = (c.flags & GLABC_FLAG_TH64) ? ((double)av + c.theta[j]) : (double)(av + (float)c.theta[j]);
+        x[j] = b + (c.grad[j] * m.tau_sq) / 2.0;                                             // :43
+    }
+    double gprop[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) thf[j] = (float)x[j];                                        // :62
+    numerical_gradient<D>(m, rng, step, 1, thf, gprop);                                      // :187
+    double y[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const float noise = a.noise_loc[j] + a.noise_scale[j] * zn[D + j];
+        y[j] = __builtin_fabs(x[j]) + (double)noise;                                         // :188-189
+    }
+    double tq[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const double arg = ((c.theta[j] - x[j]) - (gprop[j] * m.tau_sq) / 2.0) / m.tau;      // :115
+        const double e = (arg - 0.0) / 1.0;
+        tq[j] = 0.0 + 0.5 * (e * e);
+    }
+    const double lq_rev = (-0.5 * (double)D * GLABC_LOG_2PI) - aten_rowsum_f64<D>(tq);
+    double log_acc = dist_log_prob_f64<D>(a.prior, x) + model_log_kernel_f64<D>(a, y);       // :190
+    log_acc = log_acc + lq_rev;                                                              // :191
+    log_acc = log_acc - state_prior<D>(a, c);                                                // :192
+    log_acc = log_acc - state_kernel<D>(a, c);
+    log_acc = log_acc - (double)log_pro;                                                     // :193
+    const double log_u = (double)glabc_logf(u_accept);                                       // :194
+    if (log_u < log_acc) {                                                                   // :195-199
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            c.theta[j] = x[j];
+            c.y[j] = y[j];
+            c.grad[j] = gprop[j];
+        }
+        c.flags |= GLABC_FLAG_TH64;
+        return true;                         // `local` is NOT set: GLMALA.py:195-199 vs GLMCMC.py:100
+    }
+    return false;
+}
+
+// Philox blocks of candidate j: D proposal draws then D simulator draws (same layout as GLMCMC)
+template <int D>
+GLABC_DEV void candidate_draws(const Rng& rng, uint32_t step, int j, bool uniform_prop, float (&e)[D], float (&s)[D])
+{
+    constexpr int SPP = (2 * D + 3) / 4;
+    uint32_t w[4 * SPP];
+#pragma unroll
+    for (int b = 0; b < SPP; ++b) {
+        glabc_u32x4 o = glabc_philox4x32_10(rng.c0, rng.c1, step, (uint32_t)(1 + j * SPP + b), rng.k0, rng.k1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[4 * b + q] = o.v[q];
+    }
+    float nrm[2 * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        e[i] = uniform_prop ? glabc_uniform_f32(w[i]) : nrm[i];
+        s[i] = nrm[D + i];
+    }
+}
+
+// the iSIR global move of GLMALA.py:151-180
+template <int D, int N>
+GLABC_DEV bool mala_isir_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, double u_res, MalaChain<D>& c)
+{
+    const StepArgs<D>& a = m.s;
+    if (c.flags & GLABC_FLAG_LOCAL) {                                                        // :152-156
+        if (c.flags & GLABC_FLAG_TH64) {
+            c.log_w = (state_prior<D>(a, c) + state_kernel<D>(a, c)) - dist_log_prob_f64<D>(a.global, c.theta);
+            c.flags |= GLABC_FLAG_LW64;
+        } else {
+            float thf[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) thf[j] = (float)c.theta[j];
+            const float q = dist_log_prob<D>(a.global, thf);
+            c.log_w = (double)(((float)state_prior<D>(a, c) + (float)state_kernel<D>(a, c)) - q);
+        }
+    }
+    c.flags &= ~GLABC_FLAG_LOCAL;                                                            // :157
+    float th[N][D], yy[N][D], lw0[N];
+    const bool uni = a.global.kind == GLABC_DIST_UNIFORM;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        float e[D], s[D];
+        candidate_draws<D>(rng, step, j, uni, e, s);
+#pragma unroll
+        for (int q = 0; q < D; ++q) th[j][q] = a.global.p0[q] + a.global.p2[q] * e[q];       // :158
+        const float lq = dist_forward_log_p<D>(a.global, e);
+        model_simulate<D>(a, th[j], s, yy[j]);                                               // :163
+        lw0[j] = (dist_log_prob<D>(a.prior, th[j]) + model_log_kernel<D>(a, yy[j])) - lq;    // :164-165
+    }
+    int ind = -1;
+    if (c.flags & GLABC_FLAG_LW64) {
+        double w[N + 1];
+        w[0] = glabc_exp(c.log_w);
+#pragma unroll
+        for (int j = 0; j < N; ++j) w[j + 1] = glabc_exp((double)lw0[j]);                    // :169
+#pragma unroll
+        for (int k = 0; k <= N; ++k) w[k] = (w[k] != w[k]) ? 0.0 : w[k];                     // :171-172
+        const double tot = aten_rowsum_f64<N + 1>(w);                                        // :173
+        double run = 0.0;
+#pragma unroll
+        for (int k = 0; k <= N; ++k) {
+            run += w[k] / tot;
+            ind = (ind < 0 && u_res < run) ? k : ind;                                        // :174
+        }
+    } else {
+        float w[N + 1];
+        w[0] = glabc_expf((float)c.log_w);
+#pragma unroll
+        for (int j = 0; j < N; ++j) w[j + 1] = glabc_expf(lw0[j]);
+#pragma unroll
+        for (int k = 0; k <= N; ++k) w[k] = (w[k] != w[k]) ? 0.0f : w[k];
+        const float tot = aten_rowsum<N + 1>(w);
+        double run = 0.0;
+#pragma unroll
+        for (int k = 0; k <= N; ++k) {
+            run += (double)(w[k] / tot);
+            ind = (ind < 0 && u_res < run) ? k : ind;
+        }
+    }
+    const bool moved = ind > 0;                                                              // :175-179
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (ind == j + 1) {
+#pragma unroll
+            for (int q = 0; q < D; ++q) {
+                c.theta[q] = (double)th[j][q];
+                c.y[q] = (double)yy[j][q];
+            }
+            c.log_w = (double)lw0[j];
+        }
+    }
+    return moved;
+}
+
+template <int D, int N>
+__global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
+{
+    const StepArgs<D>& a = m.s;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n_chains) return;
+
+    MalaChain<D> c;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        c.theta[j] = m.theta64[j * a.stride + i];
+        c.y[j] = m.y64[j * a.stride + i];
+        c.grad[j] = m.grad[j * a.stride + i];
+    }
+    c.log_w = m.log_w64[i];
+    c.flags = a.flags[i];
+    c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
+
+    constexpr int TRI = D * (D + 1) / 2;
+    const bool mom = a.sum_theta != nullptr;
+    double s1[D], s2[TRI], sj[TRI];
+    if (mom) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) s1[j] = a.sum_theta[j * a.stride + i];
+#pragma unroll
+        for (int k = 0; k < TRI; ++k) {
+            s2[k] = a.sum_outer[k * a.stride + i];
+            sj[k] = a.sum_jump[k * a.stride + i];
+        }
+    }
+
+    const uint64_t gid = (uint64_t)(a.chain0 + i);
+    Rng rng;
+    rng.c0 = (uint32_t)gid;
+    rng.c1 = (uint32_t)(gid >> 32);
+    rng.k0 = a.seed_lo;
+    rng.k1 = a.seed_hi;
+    float* hist = a.history ? a.history + i : nullptr;
+
+    for (int t = 0; t < a.n_steps; ++t) {
+        const uint32_t step = a.step0 + (uint32_t)t;
+        float prev[D], cur[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) prev[j] = (float)c.theta[j];
+
+        glabc_u32x4 h = glabc_philox4x32_10(rng.c0, rng.c1, step, 0u, rng.k0, rng.k1);
+        const float u_branch = glabc_uniform_f32(h.v[0]);
+        bool moved;
+        if (u_branch < a.gf) {                                                               // GLMALA.py:151
+            moved = mala_isir_move<D, N>(m, rng, step, glabc_uniform_f64(h.v[2], h.v[3]), c);
+        } else {
+            float e[D], s[D], zn[2 * D];
+            candidate_draws<D>(rng, step, 0, false, e, s);
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                zn[j] = e[j];
+                zn[D + j] = s[j];
+            }
+            moved = mala_move<D>(m, rng, step, glabc_uniform_f32(h.v[1]), zn, c);
+        }
+        c.n_moves += moved ? 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < D; ++j) cur[j] = (float)c.theta[j];                              // Theta_Re is float32, :148,180,200
+
+        if (hist) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) hist[((int64_t)t * D + j) * a.hist_stride] = cur[j];
+        }
+        if (mom) {
+            int k = 0;
+#pragma unroll
+            for (int p = 0; p < D; ++p) {
+                s1[p] += (double)cur[p];
+#pragma unroll
+                for (int q = p; q < D; ++q, ++k) {
+                    s2[k] += (double)cur[p] * (double)cur[q];
+                    double dp = (double)cur[p] - (double)prev[p];
+                    double dq = (double)cur[q] - (double)prev[q];
+                    sj[k] += dp * dq;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        m.theta64[j * a.stride + i] = c.theta[j];
+        m.y64[j * a.stride + i] = c.y[j];
+        m.grad[j * a.stride + i] = c.grad[j];
+        a.theta[j * a.stride + i] = (float)c.theta[j];
+        a.y[j * a.stride + i] = (float)c.y[j];
+    }
+    m.log_w64[i] = c.log_w;
+    if (a.log_w) a.log_w[i] = (float)c.log_w;
+    a.flags[i] = c.flags;
+    if (a.n_moves) a.n_moves[i] = c.n_moves;
+    if (mom) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) a.sum_theta[j * a.stride + i] = s1[j];
+#pragma unroll
+        for (int k = 0; k < TRI; ++k) {
+            a.sum_outer[k * a.stride + i] = s2[k];
+            a.sum_jump[k * a.stride + i] = sj[k];
+        }
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(64) glmala_init_kernel(const MalaArgs<D> m)
+{
+    const StepArgs<D>& a = m.s;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n_chains) return;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        m.theta64[j * a.stride + i] = (double)a.theta[j * a.stride + i];
+        m.y64[j * a.stride + i] = (double)a.y[j * a.stride + i];
+        m.grad[j * a.stride + i] = 0.0;
+    }
+    m.log_w64[i] = 0.0;
+    a.flags[i] = GLABC_FLAG_LOCAL;                                                           // GLMALA.py:146-147
+}
+
+// host-side launcher of one theta_dim; defined in glabc_mala_dim.hip (one TU per D)
+template <int D>
+int launch_glmala_dim(int n_batch, const MalaArgs<D>& m, hipStream_t stream);
+template <int D>
+int launch_glmala_init_dim(const MalaArgs<D>& m, hipStream_t stream);
+
+}  // namespace glabc

@@ -1,0 +1,40 @@
+// glabc_mala_dim.hip -- instantiates the GLMALA kernels for ONE theta_dim (-DGLABC_DIM=d),
+// batch sizes 1..GLABC_MAX_BATCH.
+#include "glabc_mala.h"
+
+#ifndef GLABC_DIM
+#error "compile with -DGLABC_DIM=<theta_dim>"
+#endif
+
+namespace glabc {
+
+template <int D, int N>
+static int launch_mala(const MalaArgs<D>& m, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((m.s.n_chains + 63) / 64);
+    hipLaunchKernelGGL((glmala_kernel<D, N>), dim3(grid), dim3(64), 0, s, m);
+    return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
+}
+
+template <>
+int launch_glmala_dim<GLABC_DIM>(int n_batch, const MalaArgs<GLABC_DIM>& m, hipStream_t s)
+{
+    constexpr int D = GLABC_DIM;
+    switch (n_batch) {
+#define GLABC_CASE(n) case n: return launch_mala<D, n>(m, s);
+        GLABC_CASE(1) GLABC_CASE(2) GLABC_CASE(3) GLABC_CASE(4) GLABC_CASE(5) GLABC_CASE(6) GLABC_CASE(7) GLABC_CASE(8)
+        GLABC_CASE(9) GLABC_CASE(10) GLABC_CASE(11) GLABC_CASE(12) GLABC_CASE(13) GLABC_CASE(14) GLABC_CASE(15) GLABC_CASE(16)
+#undef GLABC_CASE
+    default: return GLABC_ERR_ARG;
+    }
+}
+
+template <>
+int launch_glmala_init_dim<GLABC_DIM>(const MalaArgs<GLABC_DIM>& m, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((m.s.n_chains + 63) / 64);
+    hipLaunchKernelGGL((glmala_init_kernel<GLABC_DIM>), dim3(grid), dim3(64), 0, s, m);
+    return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
+}
+
+}  // namespace glabc

@@ -1,9 +1,36 @@
 """GLMALA -- iSIR global move + MALA local move (reference: GLMALA.py:118-230).
-The fused gfx950 kernel for this sampler is not built yet (SURVEY.md section 8 rows
-a4-a6); the function exists so the package surface matches the reference and fails
-loudly rather than falling back to a CPU loop."""
+
+Same positional signature as the reference function.  The loop body (GLMALA.py:150-200) --
+including the common-random-number finite-difference gradient of GLMALA.py:46-95 -- runs in
+the fused gfx950 kernel behind ``glabc_glmala_steps`` (include/glabc.h).  Shapes, return value
+and keyword-only extras as in ``GLMCMC``.
+
+Reference behaviours that are reproduced on purpose: the chain's state
+becomes float64 after the first accepted MALA move, ``log_weight_old`` is never refreshed after
+MALA moves (B1), the cached gradient is not refreshed after iSIR moves, the prior gradient is a
+float32 finite difference (B3).  Not reproducible: the reference reseeds torch / NumPy from
+``secrets`` inside every gradient (B2), so two reference runs never agree; here the gradient noise
+is a Philox sub-stream of the run's seed.
+"""
+from . import _capi, _host, engine
 
 
 def GLMALA(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad,
-           filelocation, global_frequency=0, Importance_Proposal=None, batch_size=None, **kw):
-    raise NotImplementedError("GLMALA: HIP kernel not implemented yet (no CPU fallback by design)")
+           filelocation, global_frequency=0, Importance_Proposal=None, batch_size=None, *,
+           seed=None, device=None, chain0=0, record_history=True, stats=None, return_device=False,
+           steps_per_launch=None, verbose=True, state_out=None):
+    if Importance_Proposal is None or batch_size is None:
+        raise ValueError("GLMALA needs Importance_Proposal and batch_size (GLMALA.py:155,158)")
+    model = engine.model_descriptor(ABCset)
+    imp = Importance_Proposal.descriptor()
+    mala = _capi.Mala(float(tau), float(tau) ** 2, float(ABCset.epsilon) ** 2, int(num_grad), 0)   # GLMALA.py:43,90
+    dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
+    chains.add_mala_state()
+    hist = _host.allocate_history(num_ite, chains, record_history)
+    engine.glmala_init(model, chains)                                  # GLMALA.py:143-149
+    engine.run_glmala_steps(model, imp, mala, chains, num_ite - 1, 1, engine.draw_seed(seed), global_frequency,
+                            batch_size, history=None if hist is None else hist[1:], moments=stats,
+                            steps_per_launch=steps_per_launch)
+    if state_out is not None:
+        state_out["chains"] = chains
+    return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)

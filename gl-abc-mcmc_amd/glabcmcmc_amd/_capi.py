@@ -129,6 +129,8 @@ _P = C.POINTER
 ENTRY_POINTS = {
     "glabc_glmcmc_steps": (C.c_int, [_P(Model), _P(Dist), _P(Dist), _P(Chains), _P(Run), C.c_void_p]),
     "glabc_globalmcmc_steps": (C.c_int, [_P(Model), _P(Dist), _P(Dist), _P(Chains), _P(Run), C.c_void_p]),
+    "glabc_glmala_steps": (C.c_int, [_P(Model), _P(Dist), _P(Mala), _P(Chains), _P(Run), C.c_void_p]),
+    "glabc_glmala_init": (C.c_int, [_P(Model), _P(Chains), C.c_void_p]),
     "glabc_init_weights": (C.c_int, [_P(Model), _P(Dist), _P(Chains), C.c_void_p]),
     "glabc_dist_log_prob": (C.c_int, [_P(Dist), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_prior_log_prob": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

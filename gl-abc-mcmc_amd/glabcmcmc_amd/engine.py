@@ -65,9 +65,21 @@ class ChainBatch:
         self.flags = torch.full((self.n,), _capi.FLAG_LOCAL, dtype=torch.int32, device=device)
         self.n_moves = torch.zeros(self.n, dtype=torch.int32, device=device)
 
+        self.theta64 = self.y64 = self.log_w64 = self.grad = None
+
+    def add_mala_state(self):
+        """float64 state arrays of GLMALA (glabc_chains.theta64 / y64 / log_w64 / grad)"""
+        self.theta64 = torch.zeros(self.d, self.n, dtype=torch.float64, device=self.device)
+        self.y64 = torch.zeros(self.yd, self.n, dtype=torch.float64, device=self.device)
+        self.log_w64 = torch.zeros(self.n, dtype=torch.float64, device=self.device)
+        self.grad = torch.zeros(self.d, self.n, dtype=torch.float64, device=self.device)
+        return self
+
     def struct(self):
+        ptr = lambda t: None if t is None else t.data_ptr()          # noqa: E731
         return _capi.Chains(self.n, self.chain0, self.n, self.theta.data_ptr(), self.y.data_ptr(),
-                            self.log_w.data_ptr(), self.flags.data_ptr(), self.n_moves.data_ptr())
+                            self.log_w.data_ptr(), self.flags.data_ptr(), self.n_moves.data_ptr(),
+                            ptr(self.theta64), ptr(self.y64), ptr(self.log_w64), ptr(self.grad))
 
     def theta_rows(self):
         """(C, d) view of the current states"""
@@ -152,6 +164,44 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
                 run.moments = C.pointer(ms)
             _capi.check(fn(C.byref(model_desc), C.byref(local_desc), C.byref(global_desc), C.byref(cs), C.byref(run),
                            C.c_void_p(stream)), entry)
+            done += k
+    if moments is not None:
+        moments.steps += n_steps
+
+
+def glmala_init(model_desc, chains):
+    lib = _capi.lib()
+    cs = chains.struct()
+    stream = torch.cuda.current_stream(chains.device).cuda_stream
+    with torch.cuda.device(chains.device):
+        _capi.check(lib.glabc_glmala_init(C.byref(model_desc), C.byref(cs), C.c_void_p(stream)), "glabc_glmala_init")
+
+
+def run_glmala_steps(model_desc, importance_desc, mala, chains, n_steps, step0, seed, global_frequency, batch_size,
+                     history=None, moments=None, steps_per_launch=None):
+    """GLMALA twin of run_steps (entry point glabc_glmala_steps); `mala` is a _capi.Mala."""
+    lib = _capi.lib()
+    k_max = int(steps_per_launch or MAX_STEPS_PER_LAUNCH)
+    cs = chains.struct()
+    ms = moments.struct() if moments is not None else None
+    stream = torch.cuda.current_stream(chains.device).cuda_stream
+    done = 0
+    with torch.cuda.device(chains.device):
+        while done < n_steps:
+            k = min(k_max, n_steps - done)
+            run = _capi.Run()
+            run.seed = seed
+            run.step0 = step0 + done
+            run.n_steps = k
+            run.global_frequency = float(global_frequency)
+            run.batch_size = int(batch_size)
+            if history is not None:
+                run.history = history[done].data_ptr()
+                run.hist_stride = chains.n
+            if ms is not None:
+                run.moments = C.pointer(ms)
+            _capi.check(lib.glabc_glmala_steps(C.byref(model_desc), C.byref(importance_desc), C.byref(mala), C.byref(cs),
+                                               C.byref(run), C.c_void_p(stream)), "glabc_glmala_steps")
             done += k
     if moments is not None:
         moments.steps += n_steps

@@ -194,6 +194,24 @@ def numpy_tape(rng, T, P, d, yd, uniform_prop):
     return u, r, z
 
 
+def reference_constants(cfg):
+    """The float32 constants the reference computes on the host for this configuration, with THIS
+    machine's torch (log / exp differ in the last bits between CPU types): stored in the fixture so the
+    tests rebuild exactly the descriptors the golden chains were produced with."""
+    out = {}
+    out["c_noise_log_scale"] = torch.log(torch.tensor([0.05, 0.05]).sqrt()).numpy()                    # Mixture.py:19
+    out["c_noise_scale"] = torch.exp(torch.log(torch.tensor([0.05, 0.05]).sqrt())).numpy()
+    out["c_kern_log_scale"] = torch.log(torch.tensor([cfg["epsilon"]])).numpy()                        # Mixture.py:42-43
+    out["c_kern_scale"] = torch.exp(torch.log(torch.tensor([cfg["epsilon"]]))).numpy()
+    for tag in ("local", "global"):
+        spec = cfg[tag]
+        if spec[0] == "gauss":
+            ls = torch.log(torch.tensor(spec[2], dtype=torch.float32))
+            out["c_%s_p1" % tag] = ls.numpy()
+            out["c_%s_p2" % tag] = torch.exp(ls).numpy()
+    return out
+
+
 def run_reference(algo, cfg, theta0, y0, tape):
     model = Mixture_set(cfg["epsilon"])
     local = make_dist(cfg["local"])
@@ -244,7 +262,7 @@ def sampler_fixture(name, algo, cfg, mode):
         print("\r%s chain %d/%d" % (name, c + 1, C), end="", flush=True)
     print()
     out = dict(algo=algo, mode=mode, theta0=theta0, y0=y0, chains=chains,
-               cfg=np.array(repr(cfg)))
+               cfg=np.array(repr(cfg)), **reference_constants(cfg))
     if mode == "tape":
         out["tape_u"] = np.stack([t[0] for t in tapes])
         out["tape_r"] = np.stack([t[1] for t in tapes])
@@ -445,7 +463,7 @@ def gradient_fixture():
         finally:
             torch.manual_seed, torch.randn, np.random.seed, secrets.randbelow, torch.sqrt = saved
     np.savez_compressed(os.path.join(HERE, "glmala_gradient.npz"), theta=theta, chain=chain, step=step, grad=grads,
-                        cfg=np.array(repr(cfg)))
+                        cfg=np.array(repr(cfg)), **reference_constants(cfg))
     print("glmala_gradient: %d points" % n)
 
 

@@ -30,9 +30,25 @@ def make_dist(spec):
     raise ValueError(kind)
 
 
-def descriptors(cfg):
+def descriptors(cfg, consts=None):
+    """(model, local, global) descriptors of a test configuration.  `consts` = a golden fixture: the
+    host-computed float32 constants (exp(log_scale), log(eps) ...) are then taken from the fixture, i.e.
+    the values the reference computed on the machine that generated the golden chains -- torch's CPU
+    log / exp differ in the last bits between CPU types, and GLMALA's chains depend on them."""
     model = Mixture_set(cfg["epsilon"]).descriptor()
-    return model, make_dist(cfg["local"]).descriptor(), make_dist(cfg["global"]).descriptor()
+    local, glob = make_dist(cfg["local"]).descriptor(), make_dist(cfg["global"]).descriptor()
+    if consts is not None:
+        for j in range(2):
+            model.noise.p1[j] = float(consts["c_noise_log_scale"][j])
+            model.noise.p2[j] = float(consts["c_noise_scale"][j])
+        model.kern_log_scale = float(consts["c_kern_log_scale"][0])
+        model.kern_scale = float(consts["c_kern_scale"][0])
+        for d, tag in ((local, "local"), (glob, "global")):
+            if "c_%s_p1" % tag in consts:
+                for j in range(d.dim):
+                    d.p1[j] = float(consts["c_%s_p1" % tag][j])
+                    d.p2[j] = float(consts["c_%s_p2" % tag][j])
+    return model, local, glob
 
 
 SAMPLER_GOLDENS = [

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import oracle_lib
-from helpers import SAMPLER_GOLDENS, bits, descriptors, load_golden, make_dist
+from helpers import GLMALA_GOLDENS_EXACT, SAMPLER_GOLDENS, bits, descriptors, load_golden, make_dist, mala_params
 
 pytestmark = pytest.mark.gpu
 
@@ -66,7 +66,7 @@ def test_hip_reproduces_reference_chains(hip, name):
     reference loop visited when it was fed the same stream."""
     g = load_golden(name)
     cfg = g["cfg"]
-    model, local, glob = descriptors(cfg)
+    model, local, glob = descriptors(cfg, g)
     hist, chains, _ = hip_run(str(g["algo"]), model, local, glob, g["theta0"], g["y0"], cfg["T"], cfg["seed"],
                               cfg["gf"], cfg["N"], chain0=cfg.get("chain0", 0))
     got = np.concatenate([g["theta0"][None], hist.transpose(0, 2, 1)], axis=0)
@@ -225,6 +225,94 @@ def test_bad_arguments_are_refused(hip):
     torch.cuda.synchronize()
 
 
+# ---------------------------------------------------------------------------------- GLMALA
+def hip_glmala(model, glob, mala, theta0, y0, T, seed, gf, N, chain0=0, steps_per_launch=None, moments=False):
+    from glabcmcmc_amd import engine
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0).add_mala_state()
+    engine.glmala_init(model, chains)
+    hist = torch.empty(T, chains.d, chains.n, dtype=torch.float32, device=dev)
+    mom = engine.Moments(chains.n, chains.d, dev) if moments else None
+    engine.run_glmala_steps(model, glob, mala, chains, T, 1, seed, gf, N, history=hist, moments=mom,
+                            steps_per_launch=steps_per_launch)
+    torch.cuda.synchronize()
+    return hist.cpu().numpy(), chains, mom
+
+
+def oracle_glmala(oracle, model, glob, mala, theta0, y0, T, seed, gf, N, chain0=0, moments=False):
+    hc = oracle_lib.HostChains(theta0, y0, chain0=chain0).add_mala_state()
+    hh = np.zeros((T, theta0.shape[1], theta0.shape[0]), np.float32)
+    mom = oracle_lib.HostMoments(theta0.shape[0], theta0.shape[1]) if moments else None
+    run, keep = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh, moments=mom)
+    cs = hc.struct()
+    assert oracle.oracle_glmala_init(C.byref(model), C.byref(cs)) == 0
+    assert oracle.oracle_glmala_steps(C.byref(model), C.byref(glob), C.byref(mala), C.byref(cs), C.byref(run)) == 0
+    return hh, hc, mom
+
+
+@pytest.mark.parametrize("name", GLMALA_GOLDENS_EXACT)
+def test_hip_glmala_reproduces_reference_chains(hip, name):
+    """GLMALA kernel vs the reference's chains (reference run with a correctly rounded torch.sqrt,
+    see tests/golden/make_golden.py and DESIGN.md): bit for bit."""
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, _, glob = descriptors(cfg, g)
+    hist, chains, _ = hip_glmala(model, glob, mala_params(cfg), g["theta0"], g["y0"], cfg["T"], cfg["seed"], cfg["gf"],
+                                 cfg["N"], chain0=cfg.get("chain0", 0))
+    got = np.concatenate([g["theta0"][None], hist.transpose(0, 2, 1)], axis=0)
+    same = bits(got) == bits(g["chains"])
+    assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
+
+
+MALA_CASES = [
+    # N, gf, eps, tau, num_grad, global, chains, T
+    (5, 0.8, 0.05, 0.3, 100, ("gauss", [0, 0], [1, 1]), 512, 60),
+    (3, 0.3, 0.3, 0.25, 10, ("gauss", [0, 0], [1, 1]), 700, 150),
+    (2, 0.0, 0.3, 0.2, 7, ("gauss", [0.1, 0.2], [1.2, 0.8]), 333, 100),
+    (4, 0.5, 0.3, 0.3, 12, ("uniform", [-3, -3], [3, 3]), 640, 120),
+    (8, 0.6, 0.2, 0.3, 5, ("gauss", [0, 0], [1, 1]), 256, 100),
+    (1, 1.0, 0.3, 0.3, 4, ("gauss", [0, 0], [1, 1]), 256, 60),
+]
+
+
+@pytest.mark.parametrize("case", MALA_CASES, ids=lambda c: "N%d-gf%g-num%d-%s" % (c[0], c[1], c[4], c[5][0]))
+def test_hip_glmala_equals_oracle(hip, oracle, case):
+    N, gf, eps, tau, num, gspec, n, T = case
+    cfg = dict(epsilon=eps, tau=tau, num_grad=num, local=("gauss", [0, 0], [1, 1]), **{"global": gspec})
+    model, _, glob = descriptors(cfg)
+    mala = mala_params(cfg)
+    rng = np.random.default_rng(n + T)
+    theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, 2))).astype(np.float32)
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    hist, chains, mom = hip_glmala(model, glob, mala, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True,
+                                   steps_per_launch=37)
+    hh, hc, hm = oracle_glmala(oracle, model, glob, mala, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True)
+    same = bits(hist) == bits(hh)
+    assert same.all(), "first mismatch at (t, dim, chain) = %s" % (np.argwhere(~same)[0],)
+    # the float64 state, bit for bit
+    assert np.array_equal(chains.theta64.cpu().numpy(), hc.theta64)
+    assert np.array_equal(chains.y64.cpu().numpy(), hc.y64)
+    assert np.array_equal(chains.log_w64.cpu().numpy(), hc.log_w64)
+    assert np.array_equal(chains.grad.cpu().numpy(), hc.grad)
+    assert np.array_equal(chains.flags.cpu().numpy().astype(np.uint32), hc.flags)
+    assert np.array_equal(chains.n_moves.cpu().numpy().astype(np.uint32), hc.n_moves)
+    assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
+    assert hc.n_moves.sum() > 0
+
+
+def test_glmala_function_shapes(hip):
+    import glabcmcmc_amd as g
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    m = Mixture_set(0.3)
+    ip = g.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0]))
+    one = g.GLMALA(m, 50, torch.tensor([0.0, 0.0]), torch.tensor([[1.4, 1.6]]), 0.3, 10, None, 0.8, ip, 5, seed=3,
+                   verbose=False)
+    assert one.shape == (50, 2) and one.device.type == "cpu" and one.dtype == torch.float32
+    many = g.GLMALA(m, 30, torch.zeros(100, 2), torch.full((100, 2), 1.5), 0.3, 10, None, 0.8, ip, 5, seed=3)
+    assert many.shape == (30, 100, 2)
+
+
 # ---------------------------------------------------------------------------------- primitives
 @pytest.fixture(scope="module")
 def prim():
@@ -236,8 +324,16 @@ def test_distribution_log_prob_on_gpu(hip, prim):
     for tag in ("std", "lp", "gen", "d1", "d4", "d7", "d8"):
         loc = torch.from_numpy(prim["dg_%s_loc" % tag])
         g = distribution.DiagGaussian(len(loc), loc, torch.from_numpy(prim["dg_%s_log_scale" % tag]))
-        out = g.log_prob(torch.from_numpy(prim["dg_%s_z" % tag]).cuda()).cpu().numpy()
-        assert np.array_equal(bits(out), bits(prim["dg_%s_log_prob" % tag])), tag
+        # exp(log_scale) as the machine that produced the golden values computed it (torch's CPU exp differs in
+        # the last bit between CPU types); through the C ABI directly
+        desc = g.descriptor()
+        for j in range(desc.dim):
+            desc.p2[j] = float(prim["dg_%s_scale" % tag][j])
+        z = torch.from_numpy(prim["dg_%s_z" % tag]).cuda()
+        o = torch.empty(z.shape[0], dtype=torch.float32, device="cuda")
+        assert hip.glabc_dist_log_prob(C.byref(desc), z.data_ptr(), z.shape[0], o.data_ptr(), None) == 0
+        assert np.array_equal(bits(o.cpu().numpy()), bits(prim["dg_%s_log_prob" % tag])), tag
+        assert g.log_prob(z).shape == (z.shape[0],)                  # the host-mirror path runs too
     for tag in ("box", "inc", "d4"):
         g = distribution.Uniform(len(prim["un_%s_low" % tag]), torch.from_numpy(prim["un_%s_low" % tag]),
                                  torch.from_numpy(prim["un_%s_high" % tag]))

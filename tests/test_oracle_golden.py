@@ -129,7 +129,7 @@ def test_esjd(oracle, prim):
 def run_oracle(oracle, g, philox_chain0=None):
     """Run the oracle on a sampler golden's configuration; returns the (T+1, C, d) chains."""
     cfg = g["cfg"]
-    model, local, glob = descriptors(cfg)
+    model, local, glob = descriptors(cfg, g)
     C_, T, d = g["theta0"].shape[0], cfg["T"], 2
     ch = oracle_lib.HostChains(g["theta0"], g["y0"], chain0=cfg.get("chain0", 0))
     hist = np.zeros((T, d, C_), np.float32)
@@ -167,7 +167,7 @@ def test_sampler_chains_bit_exact(oracle, name):
 
 def run_oracle_glmala(oracle, g):
     cfg = g["cfg"]
-    model, _, glob = descriptors(cfg)
+    model, _, glob = descriptors(cfg, g)
     mala = mala_params(cfg)
     C_, T, d = g["theta0"].shape[0], cfg["T"], 2
     ch = oracle_lib.HostChains(g["theta0"], g["y0"], chain0=cfg.get("chain0", 0)).add_mala_state()
@@ -236,7 +236,7 @@ def test_glmala_gradient_matches_reference(oracle):
     their own summation cascades and MKL's log)."""
     g = load_golden("glmala_gradient")
     cfg = g["cfg"]
-    model, _, _ = descriptors(cfg)
+    model, _, _ = descriptors(cfg, g)
     mala = mala_params(cfg)
     out = np.zeros(2)
     worst = 0.0
