@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true", help="diagnostic: do not write Theta_Re rows")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default; geometry only)")
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala"],
+                    help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
+                         "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,9 +119,21 @@ def main():
 
     step_idx = [0]
 
+    from glabcmcmc_amd import _capi
+    gf = {"glmcmc": GF, "globalmcmc": 0.5, "glmala": 0.8}[args.workload]
+    mala = _capi.Mala(0.3, 0.3 ** 2, EPS ** 2, 100, 0)                  # README.md:128
+    if args.workload == "glmala":
+        chains.add_mala_state()
+        engine.glmala_init(model, chains)
+
     def one_step():
-        engine.run_steps("glabc_glmcmc_steps", model, lp, ip, chains, K, 1 + step_idx[0] * K, seed, GF, NBATCH,
-                         history=hist, moments=mom, steps_per_launch=K, lanes_per_chain=args.lanes)
+        if args.workload == "glmala":
+            engine.run_glmala_steps(model, ip, mala, chains, K, 1 + step_idx[0] * K, seed, gf, NBATCH, history=hist,
+                                    moments=mom, steps_per_launch=K)
+        else:
+            entry = "glabc_glmcmc_steps" if args.workload == "glmcmc" else "glabc_globalmcmc_steps"
+            engine.run_steps(entry, model, lp, ip, chains, K, 1 + step_idx[0] * K, seed, gf, NBATCH,
+                             history=hist, moments=mom, steps_per_launch=K, lanes_per_chain=args.lanes)
         step_idx[0] += 1
 
     def barrier():
@@ -164,7 +179,8 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_b_pmc_summary.json")) as f:
                 pmc = json.load(f)
-            if pmc["config"] == {"chains": n, "iters_per_launch": K, "history": not args.no_history}:
+            if args.workload == "glmcmc" and pmc["config"] == {"chains": n, "iters_per_launch": K,
+                                                               "history": not args.no_history}:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]["total"]
                 valu = {"source": "profiles/r01_b_pmc_summary.json (rocprofv3 --pmc, round 1)",
                         "valu_insts_per_wave_step": pmc["derived"]["valu_insts_per_wave_step"],
@@ -177,7 +193,10 @@ def main():
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "GLMCMC iSIR N=5 gf=0.9, Mixture_set eps=0.05 d=2 (BASELINE configs[1])",
+            "config": {"workload": {"glmcmc": "GLMCMC iSIR N=5 gf=0.9, Mixture_set eps=0.05 d=2 (BASELINE configs[1])",
+                                    "globalmcmc": "GlobalMCMC gf=0.5, Mixture_set eps=0.05 d=2 (BASELINE configs[0], batched)",
+                                    "glmala": "GLMALA iSIR N=5 gf=0.8 tau=0.3 num_grad=100, Mixture_set eps=0.05 d=2 "
+                                              "(BASELINE configs[2])"}[args.workload],
                        "chains_per_gpu": n, "iters_per_step": K, "batch_size": NBATCH, "history": not args.no_history,
                        "lanes_per_chain": args.lanes or "auto",
                        "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
@@ -187,14 +206,16 @@ def main():
             "moment_iters": steps_all,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "glabc::sampler_kernel<GLMCMC, D=2, N=5>", "kernel_ms": kernel_ms,
+                         "kernel": {"glmcmc": "glabc::sampler_kernel<GLMCMC, D=2, N=5>",
+                                    "globalmcmc": "glabc::sampler_kernel<GLOBAL, D=2, N=1>",
+                                    "glmala": "glabc::glmala_kernel<D=2, N=5>"}[args.workload], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_chain_step": algo_bytes / (n * K),
                          "valu": valu,
                          "note": "the step is VALU-issue-bound, not HBM-bound: ~1450 vector instructions per chain-"
                                  "step against 8 algorithmic bytes (Philox + Box-Muller + densities); see DESIGN.md"},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "glmcmc":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,0 +1,260 @@
+// glabc_nf.hip -- RealNVP affine-coupling stack of GLMCMC_NF on the gfx950 matrix cores.
+//
+// Reference: GLMCMC_NFs.py:51-61 builds num_layers x [AffineCouplingBlock(MLP([1,128,128,2])), Permute(2,'swap')]
+// with the third-party normflows package and uses NF_model.sample(n) (forward through every coupling,
+// GLMCMC_NFs.py:70-72,125-127) and NF_model.log_prob(x) (inverse through every coupling, :96-98).
+// normflows is not vendored in the reference tree; its published semantics are restated in DESIGN.md /
+// SURVEY.md appendix C.  For theta_dim = 2 one coupling is, per row z = (z0, z1):
+//     h1 = relu(W1 z0 + b1)            1 -> 128
+//     h2 = relu(W2 h1 + b2)            128 x 128   <-- the only dense contraction on the whole hot path
+//     (shift, log_s) = W3 h2 + b3      128 -> 2
+//     forward: z1 <- z1*exp(log_s) + shift, log_det = +log_s ; inverse: z1 <- (z1 - shift)*exp(-log_s), log_det = -log_s
+//     swap:    z <- (z1, z0)
+//
+// Mapping.  One wavefront owns a tile of 32 rows.  The 128x128 layer runs on v_mfma_f32_32x32x2_f32 with
+// D[i][j] = sum_k A[i][k] B[k][j]:  i = output neuron (4 tiles of 32), j = row, k = input neuron, so
+//     A: lane l holds W2[32t + (l&31)][2s + (l>>5)]   one float from the LDS image of W2^T ([k][i], conflict-free)
+//     B: lane l holds h1[row l&31][2s + (l>>5)]        computed once per coupling into 64 VGPRs
+//     D: lane l holds, for ITS row (l&31), the 16 neurons i = 32t + (r&3) + 8(r>>2) + 4(l>>5), r = 0..15
+// i.e. the two lanes l and l+32 of a row each end up with half of the hidden units, reduce them against W3
+// in registers (64-term fmaf chains) and exchange the two partial sums with one ds_swizzle.  f32-input MFMA is
+// exact float32 (bit-for-bit a k-ordered fmaf chain, MI355X_MICROARCH.md), so the CPU checker reproduces every
+// output bit.  Weights of the current coupling live in LDS (W2^T 64 KiB + 3 KiB of vectors); a workgroup of
+// 4 waves pushes ROWS_PER_WG rows through a coupling before the next coupling's weights are staged.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/glabc.h"
+#include "../../include/glabc_numerics.h"
+
+namespace glabc {
+
+constexpr int NF_H = 128;                                     // hidden width, GLMCMC_NFs.py:56
+constexpr int NF_W2_OFF = 0;                                  // layout of one coupling's parameter block (floats)
+constexpr int NF_W1_OFF = NF_H * NF_H;                        //   W2^T [k][i] | W1 | b1 | (b2, W3[0], W3[1], 0)[i] | b3[2] pad[2]
+constexpr int NF_B1_OFF = NF_W1_OFF + NF_H;
+constexpr int NF_V4_OFF = NF_B1_OFF + NF_H;
+constexpr int NF_B3_OFF = NF_V4_OFF + 4 * NF_H;
+constexpr int NF_BLOCK_FLOATS = NF_B3_OFF + 4;                // = GLABC_NF_COUPLING_FLOATS
+static_assert(NF_BLOCK_FLOATS == GLABC_NF_COUPLING_FLOATS, "parameter block layout");
+
+constexpr int NF_WAVES = 4;
+constexpr int NF_TILES_PER_WAVE = 4;                          // 32-row tiles a wave pushes through per weight staging
+constexpr int NF_ROWS_PER_WG = 32 * NF_WAVES * NF_TILES_PER_WAVE;     // 512
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct NfArgs {
+    const float* params;          // [n_couplings][NF_BLOCK_FLOATS]
+    int32_t n_couplings;
+    float base_loc[2], base_log_scale[2], base_scale[2], base_c0;
+    // inputs / outputs, chain-major [2][n]
+    const float* in;              // forward: base noise eps (NULL = Philox);  inverse: x
+    float* z_out;                 // forward: samples ; inverse: unused (NULL)
+    float* log_q;                 // [n]
+    int64_t n_rows, row0;
+    uint32_t seed_lo, seed_hi;
+};
+
+// (shift, log_s) of one coupling for this lane's row, conditioner input z0.  lds = staged parameter block.
+__device__ __forceinline__ void coupling_params(const float* __restrict__ lds, float z0, int lane, float& shift, float& log_s)
+{
+    const int half = lane >> 5, col = lane & 31;
+    // h1 for k = 2s + half, s = 0..63 (the B operand of every MFMA of this coupling)
+    float h1[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const int k = 2 * s + half;
+        h1[s] = __builtin_fmaxf(__builtin_fmaf(lds[NF_W1_OFF + k], z0, lds[NF_B1_OFF + k]), 0.0f);
+    }
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float* wt = lds + NF_W2_OFF + 32 * t + col;                 // W2^T[k][32t + col]
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            const float a = wt[(2 * s + half) * NF_H];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float4 v = *reinterpret_cast<const float4*>(lds + NF_V4_OFF + 4 * i);     // (b2, W3[0], W3[1], 0)
+            const float h2 = __builtin_fmaxf(acc[r] + v.x, 0.0f);
+            p0 = __builtin_fmaf(v.y, h2, p0);
+            p1 = __builtin_fmaf(v.z, h2, p1);
+        }
+    }
+    // partial sums of the two halves of the row: lane l <-> l + 32
+    const float q0 = __shfl_xor(p0, 32, 64), q1 = __shfl_xor(p1, 32, 64);
+    const float lo0 = half ? q0 : p0, hi0 = half ? p0 : q0;
+    const float lo1 = half ? q1 : p1, hi1 = half ? p1 : q1;
+    shift = (lo0 + hi0) + lds[NF_B3_OFF + 0];
+    log_s = (lo1 + hi1) + lds[NF_B3_OFF + 1];
+}
+
+template <bool INVERSE>
+__global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31;
+    const int64_t wg_row0 = (int64_t)blockIdx.x * NF_ROWS_PER_WG;
+
+    // this lane's rows: tile q of the wave -> row wg_row0 + (wave*TILES + q)*32 + col
+    float z0[NF_TILES_PER_WAVE], z1[NF_TILES_PER_WAVE], lq[NF_TILES_PER_WAVE];
+    bool valid[NF_TILES_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < NF_TILES_PER_WAVE; ++q) {
+        const int64_t row = wg_row0 + (int64_t)(wave * NF_TILES_PER_WAVE + q) * 32 + col;
+        valid[q] = row < a.n_rows;
+        const int64_t rr = valid[q] ? row : a.n_rows - 1;
+        if (INVERSE) {
+            z0[q] = a.in[rr];
+            z1[q] = a.in[a.n_rows + rr];
+            lq[q] = 0.0f;
+        } else {
+            float e0, e1;
+            if (a.in) {
+                e0 = a.in[rr];
+                e1 = a.in[a.n_rows + rr];
+            } else {
+                const uint64_t gid = (uint64_t)(a.row0 + rr);
+                glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, 0u, a.seed_lo, a.seed_hi);
+                glabc_normal_pair(w.v[0], w.v[1], &e0, &e1);
+            }
+            // base DiagGaussian(2).forward: z = loc + exp(log_scale)*eps ; log_p = C - sum(log_scale + 0.5 eps^2)
+            z0[q] = a.base_loc[0] + a.base_scale[0] * e0;
+            z1[q] = a.base_loc[1] + a.base_scale[1] * e1;
+            lq[q] = a.base_c0 - ((a.base_log_scale[0] + 0.5f * (e0 * e0)) + (a.base_log_scale[1] + 0.5f * (e1 * e1)));
+        }
+    }
+
+    for (int cc = 0; cc < a.n_couplings; ++cc) {
+        const int c = INVERSE ? (a.n_couplings - 1 - cc) : cc;
+        __syncthreads();                                               // everyone is done with the previous block
+        {
+            const float4* src = reinterpret_cast<const float4*>(a.params + (int64_t)c * NF_BLOCK_FLOATS);
+            float4* dst = reinterpret_cast<float4*>(lds);
+            for (int i = threadIdx.x; i < NF_BLOCK_FLOATS / 4; i += 64 * NF_WAVES) dst[i] = src[i];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int q = 0; q < NF_TILES_PER_WAVE; ++q) {
+            float shift, log_s;
+            if (INVERSE) {
+                // flows reversed: Permute^-1 (the swap again) then the coupling's inverse
+                const float t0 = z1[q], t1 = z0[q];
+                coupling_params(lds, t0, lane, shift, log_s);
+                z0[q] = t0;
+                z1[q] = (t1 - shift) * glabc_expf(-log_s);
+                lq[q] = lq[q] + (-log_s);
+            } else {
+                coupling_params(lds, z0[q], lane, shift, log_s);
+                const float nz = z1[q] * glabc_expf(log_s) + shift;
+                lq[q] = lq[q] - log_s;                                 // log_q -= log_det
+                z1[q] = z0[q];                                         // Permute(2, 'swap')
+                z0[q] = nz;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < NF_TILES_PER_WAVE; ++q) {
+        const int64_t row = wg_row0 + (int64_t)(wave * NF_TILES_PER_WAVE + q) * 32 + col;
+        if (valid[q] && lane < 32) {
+            if (INVERSE) {
+                // + q0.log_prob(z): C - sum(log_scale + 0.5 ((z - loc)/exp(log_scale))^2)
+                const float e0 = (z0[q] - a.base_loc[0]) / a.base_scale[0], e1 = (z1[q] - a.base_loc[1]) / a.base_scale[1];
+                const float lp = a.base_c0 - ((a.base_log_scale[0] + 0.5f * (e0 * e0)) + (a.base_log_scale[1] + 0.5f * (e1 * e1)));
+                a.log_q[row] = lq[q] + lp;
+            } else {
+                a.z_out[row] = z0[q];
+                a.z_out[a.n_rows + row] = z1[q];
+                a.log_q[row] = lq[q];
+            }
+        }
+    }
+}
+
+}  // namespace glabc
+
+using namespace glabc;
+
+static int nf_check(const glabc_flow* f, const float* io, float* log_q, int64_t n)
+{
+    if (!f || !f->params || !log_q) return GLABC_ERR_NULL;
+    (void)io;
+    if (f->n_couplings < 1 || f->n_couplings > 4096 || f->hidden != NF_H) return GLABC_ERR_ARG;
+    if (n < 0) return GLABC_ERR_ARG;
+    for (int j = 0; j < 2; ++j)
+        if (!std::isfinite(f->base_loc[j]) || !std::isfinite(f->base_log_scale[j]) || !(f->base_scale[j] > 0.0f)) return GLABC_ERR_ARG;
+    return GLABC_OK;
+}
+
+static NfArgs nf_pack(const glabc_flow* f, const float* in, float* z, float* log_q, int64_t n, uint64_t seed, int64_t row0)
+{
+    NfArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.params = f->params;
+    a.n_couplings = f->n_couplings;
+    for (int j = 0; j < 2; ++j) {
+        a.base_loc[j] = f->base_loc[j];
+        a.base_log_scale[j] = f->base_log_scale[j];
+        a.base_scale[j] = f->base_scale[j];
+    }
+    a.base_c0 = f->base_c0;
+    a.in = in;
+    a.z_out = z;
+    a.log_q = log_q;
+    a.n_rows = n;
+    a.row0 = row0;
+    a.seed_lo = (uint32_t)seed;
+    a.seed_hi = (uint32_t)(seed >> 32);
+    return a;
+}
+
+template <bool INV>
+static int nf_launch(const NfArgs& a, hipStream_t s)
+{
+    const size_t lds_bytes = sizeof(float) * NF_BLOCK_FLOATS;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[INV]) {
+        if (hipFuncSetAttribute((const void*)nf_kernel<INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return GLABC_ERR_LAUNCH;
+        attr_set[INV] = true;
+    }
+    const unsigned grid = (unsigned)((a.n_rows + NF_ROWS_PER_WG - 1) / NF_ROWS_PER_WG);
+    hipLaunchKernelGGL((nf_kernel<INV>), dim3(grid), dim3(64 * NF_WAVES), lds_bytes, s, a);
+    return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
+}
+
+extern "C" {
+
+__attribute__((visibility("default"))) int glabc_nf_sample(const glabc_flow* flow, const float* eps, uint64_t seed, int64_t row0,
+                                                           int64_t n_rows, float* z_out, float* log_q, void* stream)
+{
+    int rc = nf_check(flow, eps, log_q, n_rows);
+    if (rc) return rc;
+    if (!z_out) return GLABC_ERR_NULL;
+    if (n_rows == 0) return GLABC_OK;
+    return nf_launch<false>(nf_pack(flow, eps, z_out, log_q, n_rows, seed, row0), (hipStream_t)stream);
+}
+
+__attribute__((visibility("default"))) int glabc_nf_log_prob(const glabc_flow* flow, const float* x, int64_t n_rows, float* log_q,
+                                                             void* stream)
+{
+    int rc = nf_check(flow, x, log_q, n_rows);
+    if (rc) return rc;
+    if (!x) return GLABC_ERR_NULL;
+    if (n_rows == 0) return GLABC_OK;
+    return nf_launch<true>(nf_pack(flow, x, nullptr, log_q, n_rows, 0, 0), (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -86,6 +86,24 @@ class Mala(C.Structure):
     ]
 
 
+NF_HIDDEN = 128
+NF_COUPLING_FLOATS = 128 * 128 + 128 + 128 + 4 * 128 + 4
+
+
+class Flow(C.Structure):
+    """struct glabc_flow"""
+    _fields_ = [
+        ("n_couplings", C.c_int32),
+        ("hidden", C.c_int32),
+        ("params", C.c_void_p),
+        ("base_loc", C.c_float * 2),
+        ("base_log_scale", C.c_float * 2),
+        ("base_scale", C.c_float * 2),
+        ("base_c0", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
 class Moments(C.Structure):
     """struct glabc_moments"""
     _fields_ = [
@@ -131,6 +149,8 @@ ENTRY_POINTS = {
     "glabc_globalmcmc_steps": (C.c_int, [_P(Model), _P(Dist), _P(Dist), _P(Chains), _P(Run), C.c_void_p]),
     "glabc_glmala_steps": (C.c_int, [_P(Model), _P(Dist), _P(Mala), _P(Chains), _P(Run), C.c_void_p]),
     "glabc_glmala_init": (C.c_int, [_P(Model), _P(Chains), C.c_void_p]),
+    "glabc_nf_sample": (C.c_int, [_P(Flow), C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "glabc_nf_log_prob": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_init_weights": (C.c_int, [_P(Model), _P(Dist), _P(Chains), C.c_void_p]),
     "glabc_dist_log_prob": (C.c_int, [_P(Dist), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_prior_log_prob": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

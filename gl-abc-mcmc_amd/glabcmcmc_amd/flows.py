@@ -1,0 +1,152 @@
+"""RealNVP proposal of GLMCMC_NF (reference: GLMCMC_NFs.py:51-61) without the normflows dependency.
+
+The reference builds ``nf.NormalizingFlow(base, [AffineCouplingBlock(MLP([1,128,128,2], init_zeros=True)),
+Permute(2, 'swap')] * num_layers)`` from the third-party ``normflows`` package (not vendored, not installable
+offline).  ``RealNVP`` restates that model's published semantics as a plain ``torch.nn.Module``:
+
+* ``forward_kld`` / autograd training run on stock PyTorch ops (GLMCMC_NFs.py:112-124 stays autograd);
+* ``sample(n)`` and ``log_prob(x)`` on a CUDA flow run the hand-written matrix-core kernels behind
+  ``glabc_nf_sample`` / ``glabc_nf_log_prob`` (exact-float32 MFMA, include/glabc.h); ``sample_torch`` /
+  ``log_prob_torch`` are the same maps in eager PyTorch (training-time graph, CPU use, cross-checks).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+HIDDEN = _capi.NF_HIDDEN
+
+
+class BaseDiagGaussian(nn.Module):
+    """nf.distributions.base.DiagGaussian(2): trainable loc / log_scale of shape (1, d), zeros."""
+
+    def __init__(self, d=2):
+        super().__init__()
+        self.d = d
+        self.loc = nn.Parameter(torch.zeros(1, d))
+        self.log_scale = nn.Parameter(torch.zeros(1, d))
+
+    def forward(self, num_samples=1):
+        eps = torch.randn(num_samples, self.d, dtype=self.loc.dtype, device=self.loc.device)
+        z = self.loc + torch.exp(self.log_scale) * eps
+        log_p = -0.5 * self.d * np.log(2 * np.pi) - torch.sum(self.log_scale + 0.5 * torch.pow(eps, 2), 1)
+        return z, log_p
+
+    def log_prob(self, z):
+        return -0.5 * self.d * np.log(2 * np.pi) - torch.sum(
+            self.log_scale + 0.5 * torch.pow((z - self.loc) / torch.exp(self.log_scale), 2), 1)
+
+
+class Coupling(nn.Module):
+    """AffineCouplingBlock(MLP([1, 128, 128, 2], init_zeros=True)) for theta_dim = 2."""
+
+    def __init__(self):
+        super().__init__()
+        self.l1, self.l2, self.l3 = nn.Linear(1, HIDDEN), nn.Linear(HIDDEN, HIDDEN), nn.Linear(HIDDEN, 2)
+        nn.init.zeros_(self.l3.weight)                  # init_zeros=True, GLMCMC_NFs.py:56
+        nn.init.zeros_(self.l3.bias)
+
+    def params(self, z0):
+        p = self.l3(torch.relu(self.l2(torch.relu(self.l1(z0)))))      # LeakyReLU(0.0) == ReLU
+        return p[:, 0:1], p[:, 1:2]                     # shift = param[:, 0::2], log-scale = param[:, 1::2]
+
+
+class RealNVP(nn.Module):
+    def __init__(self, num_layers=32, base=None):
+        super().__init__()
+        self.q0 = base if base is not None else BaseDiagGaussian(2)
+        self.couplings = nn.ModuleList([Coupling() for _ in range(num_layers)])
+
+    # ---- eager PyTorch (autograd) ------------------------------------------------------------------
+    def sample_torch(self, num_samples=1, eps=None):
+        if eps is None:
+            z, log_q = self.q0(num_samples)
+        else:
+            z = self.q0.loc + torch.exp(self.q0.log_scale) * eps
+            log_q = -0.5 * 2 * np.log(2 * np.pi) - torch.sum(self.q0.log_scale + 0.5 * torch.pow(eps, 2), 1)
+        for c in self.couplings:
+            z0, z1 = z[:, 0:1], z[:, 1:2]
+            shift, log_s = c.params(z0)
+            z1 = z1 * torch.exp(log_s) + shift
+            log_q = log_q - log_s[:, 0]
+            z = torch.cat([z1, z0], dim=1)              # Permute(2, 'swap')
+        return z, log_q
+
+    def log_prob_torch(self, x):
+        z = x
+        log_q = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
+        for c in reversed(self.couplings):
+            z0, z1 = z[:, 1:2], z[:, 0:1]               # undo the swap
+            shift, log_s = c.params(z0)
+            z1 = (z1 - shift) * torch.exp(-log_s)
+            log_q = log_q - log_s[:, 0]
+            z = torch.cat([z0, z1], dim=1)
+        return log_q + self.q0.log_prob(z)
+
+    def forward_kld(self, x):
+        return -torch.mean(self.log_prob_torch(x))
+
+    # ---- matrix-core kernels -----------------------------------------------------------------------
+    def packed_params(self):
+        """[n_couplings][GLABC_NF_COUPLING_FLOATS] float32 blob in the layout of include/glabc.h"""
+        blocks = []
+        for c in self.couplings:
+            w2t = c.l2.weight.detach().t().contiguous().reshape(-1)            # W2^T [k][i]
+            v4 = torch.stack([c.l2.bias.detach(), c.l3.weight.detach()[0], c.l3.weight.detach()[1],
+                              torch.zeros_like(c.l2.bias)], dim=1).reshape(-1)
+            b3 = torch.cat([c.l3.bias.detach(), torch.zeros(2, device=c.l3.bias.device)])
+            blocks.append(torch.cat([w2t, c.l1.weight.detach()[:, 0], c.l1.bias.detach(), v4, b3]))
+        blob = torch.stack(blocks).to(torch.float32).contiguous()
+        assert blob.shape[1] == _capi.NF_COUPLING_FLOATS
+        return blob
+
+    def descriptor(self, blob):
+        f = _capi.Flow()
+        f.n_couplings, f.hidden, f.params = len(self.couplings), HIDDEN, blob.data_ptr()
+        loc = self.q0.loc.detach().reshape(-1).float().cpu()
+        ls = self.q0.log_scale.detach().reshape(-1).float().cpu()
+        sc = torch.exp(ls)
+        for j in range(2):
+            f.base_loc[j], f.base_log_scale[j], f.base_scale[j] = float(loc[j]), float(ls[j]), float(sc[j])
+        f.base_c0 = float(np.float32(-0.5 * 2 * np.log(2 * np.pi)))
+        return f
+
+    def _device(self):
+        return next(self.parameters()).device
+
+    @torch.no_grad()
+    def sample(self, num_samples=1, eps=None, seed=0, row0=0):
+        """NF_model.sample(n) -> (z (n, 2), log_q (n,)).  On CUDA: glabc_nf_sample (MFMA); eps (n, 2) optional
+        base noise, otherwise Philox(seed, row0 + r)."""
+        dev = self._device()
+        if dev.type != "cuda":
+            return self.sample_torch(num_samples, eps)
+        blob = self.packed_params()
+        f = self.descriptor(blob)
+        n = int(num_samples)
+        e = None if eps is None else eps.detach().to(dev, torch.float32).t().contiguous()
+        z = torch.empty(2, n, dtype=torch.float32, device=dev)
+        lq = torch.empty(n, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _capi.check(_capi.lib().glabc_nf_sample(C.byref(f), None if e is None else e.data_ptr(), int(seed), int(row0), n,
+                                                    z.data_ptr(), lq.data_ptr(), C.c_void_p(stream)), "glabc_nf_sample")
+        return z.t(), lq
+
+    @torch.no_grad()
+    def log_prob(self, x):
+        dev = self._device()
+        if dev.type != "cuda":
+            return self.log_prob_torch(x)
+        blob = self.packed_params()
+        f = self.descriptor(blob)
+        xx = x.detach().to(dev, torch.float32).reshape(-1, 2).t().contiguous()
+        lq = torch.empty(xx.shape[1], dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _capi.check(_capi.lib().glabc_nf_log_prob(C.byref(f), xx.data_ptr(), xx.shape[1], lq.data_ptr(),
+                                                      C.c_void_p(stream)), "glabc_nf_log_prob")
+        return lq

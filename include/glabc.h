@@ -189,6 +189,36 @@ int glabc_glmala_steps(const glabc_model* model, const glabc_dist* importance, c
 /* GLMALA.py:143-149: theta64 / y64 <- theta / y, flags <- LOCAL, no gradient yet. */
 int glabc_glmala_init(const glabc_model* model, const glabc_chains* chains, void* stream);
 
+/* ---- RealNVP coupling stack of GLMCMC_NF (GLMCMC_NFs.py:51-61,70-72,96-98) -------------------------
+ * theta_dim = 2, hidden width 128 (nf.nets.MLP([1, 128, 128, 2]), GLMCMC_NFs.py:56).  One coupling's
+ * parameters are one block of GLABC_NF_COUPLING_FLOATS floats in DEVICE memory:
+ *     W2^T [k][i] (128*128, input-major) | W1[128] | b1[128] | (b2[i], W3[0][i], W3[1][i], 0) x 128 | b3[2], 0, 0
+ * (W1: Linear(1,128).weight[:,0]; W2: Linear(128,128).weight [out][in]; W3: Linear(128,2).weight; row 0 of the
+ * last layer is the shift, row 1 the log-scale: normflows AffineCoupling, param[:, 0::2] / param[:, 1::2]).
+ * Rows are chain-major: x[0*n + r], x[1*n + r]. */
+#define GLABC_NF_HIDDEN 128
+#define GLABC_NF_COUPLING_FLOATS (128 * 128 + 128 + 128 + 4 * 128 + 4)
+
+typedef struct glabc_flow {
+    int32_t n_couplings;           /* GLMCMC_NFs.py:51 num_layers (32 there) */
+    int32_t hidden;                /* must be GLABC_NF_HIDDEN */
+    const float* params;           /* device, [n_couplings][GLABC_NF_COUPLING_FLOATS] */
+    float base_loc[2];             /* nf.distributions.base.DiagGaussian(2): loc, log_scale, exp(log_scale) */
+    float base_log_scale[2];
+    float base_scale[2];
+    float base_c0;                 /* f32(-0.5*2*log(2 pi)) */
+    int32_t reserved;
+} glabc_flow;
+
+/* NF_model.sample(n): z = base(eps) pushed FORWARD through every coupling + swap; log_q = base log-density minus
+ * the accumulated log-determinants.  eps[2][n] = the base noise, or NULL to draw it from Philox
+ * (key = seed, counter = (row0 + r, 0, 0)). */
+int glabc_nf_sample(const glabc_flow* flow, const float* eps, uint64_t seed, int64_t row0, int64_t n_rows,
+                    float* z_out, float* log_q, void* stream);
+
+/* NF_model.log_prob(x): x pulled back through the couplings in reverse order (inverse pass) + base log_prob. */
+int glabc_nf_log_prob(const glabc_flow* flow, const float* x, int64_t n_rows, float* log_q, void* stream);
+
 /* GLMCMC.py:52-55 -- (re)initialise log_w = prior + log-kernel - q(theta) and set
  * GLABC_FLAG_LOCAL for every chain. */
 int glabc_init_weights(const glabc_model* model, const glabc_dist* importance,

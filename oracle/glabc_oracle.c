@@ -944,6 +944,99 @@ ORACLE_API int oracle_glmala_steps(const glabc_model* m, const glabc_dist* imp, 
     return 0;
 }
 
+
+/* ========================================================================= */
+/* RealNVP coupling stack of GLMCMC_NF (GLMCMC_NFs.py:51-61,70-72,96-98).     */
+/* normflows is a third-party dependency that is not in the reference tree    */
+/* (setup.py:12 `normflows>=1.7.2`, unpinned) and cannot be installed here, so */
+/* its published forward / inverse semantics are restated: this   */
+/* part of the oracle is NOT pinned by reference outputs ("parity unpinned").  */
+/* The arithmetic order is spelled out so that the matrix-core kernel can be   */
+/* checked bit for bit: the 128x128 layer is a k-ascending fmaf chain from 0   */
+/* (what v_mfma_f32_32x32x2_f32 computes), the 128->2 layer is two 64-term     */
+/* fmaf chains over the hidden units with bit 2 of their index clear / set, in */
+/* the order i = 32t + (r&3) + 8(r>>2) + 4h, t = 0..3, r = 0..15, then added.  */
+/* ========================================================================= */
+#define NF_H 128
+#define NF_W1_OFF (NF_H * NF_H)
+#define NF_B1_OFF (NF_W1_OFF + NF_H)
+#define NF_V4_OFF (NF_B1_OFF + NF_H)
+#define NF_B3_OFF (NF_V4_OFF + 4 * NF_H)
+
+static void nf_coupling_params(const float* blk, float z0, float* shift, float* log_s)
+{
+    float h1[NF_H], part[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    for (int k = 0; k < NF_H; ++k) h1[k] = fmaxf(__builtin_fmaf(blk[NF_W1_OFF + k], z0, blk[NF_B1_OFF + k]), 0.0f);
+    for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 4; ++t)
+            for (int r = 0; r < 16; ++r) {
+                int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float acc = 0.0f;
+                for (int k = 0; k < NF_H; ++k) acc = __builtin_fmaf(blk[k * NF_H + i], h1[k], acc);      /* W2^T[k][i] */
+                const float* v = blk + NF_V4_OFF + 4 * i;                                                 /* (b2, W3[0], W3[1], 0) */
+                float h2 = fmaxf(acc + v[0], 0.0f);
+                part[h][0] = __builtin_fmaf(v[1], h2, part[h][0]);
+                part[h][1] = __builtin_fmaf(v[2], h2, part[h][1]);
+            }
+    *shift = (part[0][0] + part[1][0]) + blk[NF_B3_OFF + 0];
+    *log_s = (part[0][1] + part[1][1]) + blk[NF_B3_OFF + 1];
+}
+
+/* NF_model.sample: eps[2][n] (or NULL = Philox) -> z[2][n], log_q[n]; params are HOST pointers here */
+ORACLE_API int oracle_nf_sample(const glabc_flow* f, const float* eps, uint64_t seed, int64_t row0, int64_t n, float* z,
+                                float* log_q)
+{
+    if (!f || !f->params || !z || !log_q) return GLABC_ERR_NULL;
+    if (f->hidden != NF_H || f->n_couplings < 1) return GLABC_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+        float e0, e1;
+        if (eps) {
+            e0 = eps[r];
+            e1 = eps[n + r];
+        } else {
+            uint64_t gid = (uint64_t)(row0 + r);
+            glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+            glabc_normal_pair(w.v[0], w.v[1], &e0, &e1);
+        }
+        float z0 = f->base_loc[0] + f->base_scale[0] * e0, z1 = f->base_loc[1] + f->base_scale[1] * e1;
+        float lq = f->base_c0 - ((f->base_log_scale[0] + 0.5f * (e0 * e0)) + (f->base_log_scale[1] + 0.5f * (e1 * e1)));
+        for (int c = 0; c < f->n_couplings; ++c) {
+            float shift, log_s;
+            nf_coupling_params(f->params + (int64_t)c * GLABC_NF_COUPLING_FLOATS, z0, &shift, &log_s);
+            float nz = z1 * glabc_expf(log_s) + shift;
+            lq = lq - log_s;
+            z1 = z0;
+            z0 = nz;
+        }
+        z[r] = z0;
+        z[n + r] = z1;
+        log_q[r] = lq;
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_nf_log_prob(const glabc_flow* f, const float* x, int64_t n, float* log_q)
+{
+    if (!f || !f->params || !x || !log_q) return GLABC_ERR_NULL;
+    if (f->hidden != NF_H || f->n_couplings < 1) return GLABC_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+        float z0 = x[r], z1 = x[n + r], lq = 0.0f;
+        for (int c = f->n_couplings - 1; c >= 0; --c) {
+            float t0 = z1, t1 = z0, shift, log_s;
+            nf_coupling_params(f->params + (int64_t)c * GLABC_NF_COUPLING_FLOATS, t0, &shift, &log_s);
+            z0 = t0;
+            z1 = (t1 - shift) * glabc_expf(-log_s);
+            lq = lq + (-log_s);
+        }
+        float e0 = (z0 - f->base_loc[0]) / f->base_scale[0], e1 = (z1 - f->base_loc[1]) / f->base_scale[1];
+        float lp = f->base_c0 - ((f->base_log_scale[0] + 0.5f * (e0 * e0)) + (f->base_log_scale[1] + 0.5f * (e1 * e1)));
+        log_q[r] = lq + lp;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* ESJD.py:2-25 : det( D^T D / (n-1) )^(1/d), D = consecutive differences, all float32.
  * torch.det is an LU with partial pivoting; restated for d <= GLABC_MAX_DIM.
