@@ -74,6 +74,60 @@ def cpu_baseline(seconds_target=12.0):
                       "iterations of the bench workload" % (cores, n, T)}
 
 
+def bench_nf(args):
+    """BASELINE configs[4]: RealNVP global proposal, 8 couplings x MLP[1,128,128,2], 65 536 chains x N=5 =
+    327 680 rows per global step, on the f32 matrix cores.  One step = NF_model.sample(rows) + NF_model.log_prob
+    of 65 536 current states (what one global step of GLMCMC_NF evaluates, GLMCMC_NFs.py:70-72,96-98)."""
+    from glabcmcmc_amd.flows import RealNVP
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    flow = RealNVP(args.couplings)
+    with torch.no_grad():
+        for c in flow.couplings:
+            c.l3.weight.normal_(0, 0.3 / 128 ** 0.5)
+            c.l3.bias.normal_(0, 0.1)
+    flow = flow.cuda()
+    rows, cur = args.chains * NBATCH, args.chains
+    blob = flow.packed_params()
+    f = flow.descriptor(blob)
+    from glabcmcmc_amd import _capi
+    lib = _capi.lib()
+    z = torch.empty(2, rows, dtype=torch.float32, device="cuda")
+    lq = torch.empty(rows, dtype=torch.float32, device="cuda")
+    x = torch.randn(2, cur, device="cuda")
+    lp = torch.empty(cur, dtype=torch.float32, device="cuda")
+
+    def one_step(i):
+        _capi.check(lib.glabc_nf_sample(C.byref(f), None, 1234, i * rows, rows, z.data_ptr(), lq.data_ptr(), None), "nf_sample")
+        _capi.check(lib.glabc_nf_log_prob(C.byref(f), x.data_ptr(), cur, lp.data_ptr(), None), "nf_log_prob")
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i, (a, b) in enumerate(ev):
+        a.record()
+        one_step(i)
+        b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    flop = 2.0 * (128 + 128 * 128 + 2 * 128) * args.couplings * (rows + cur)        # 2*(1x128 + 128x128 + 128x2) per row-coupling
+    mfma_flop = 2.0 * 128 * 128 * args.couplings * (rows + cur)
+    out = {"metric": "NF proposal rows/sec (sample + log_prob), RealNVP %d couplings" % args.couplings,
+           "value": (rows + cur) * args.steps / elapsed, "unit": "rows/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "GLMCMC_NF coupling stack: %d couplings x MLP[1,128,128,2], %d sample rows + %d log_prob rows"
+                                  " per step (BASELINE configs[4])" % (args.couplings, rows, cur)},
+           "roofline": {"bound": "mfma", "achieved": mfma_flop / (kernel_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": mfma_flop / (kernel_ms * 1e-3) / 1e12 / 157.3, "traffic": None,
+                        "kernel": "glabc::nf_kernel<forward> + <inverse> (v_mfma_f32_32x32x2_f32)", "kernel_ms": kernel_ms,
+                        "all_flop_TFLOPs": flop / (kernel_ms * 1e-3) / 1e12}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,10 +138,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true", help="diagnostic: do not write Theta_Re rows")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default; geometry only)")
-    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala"],
+    ap.add_argument("--couplings", type=int, default=8, help="nf workload: number of couplings")
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
+    if args.workload == "nf":
+        return bench_nf(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -14,7 +14,7 @@
 // Mapping.  One wavefront owns a tile of 32 rows.  The 128x128 layer runs on v_mfma_f32_32x32x2_f32 with
 // D[i][j] = sum_k A[i][k] B[k][j]:  i = output neuron (4 tiles of 32), j = row, k = input neuron, so
 //     A: lane l holds W2[32t + (l&31)][2s + (l>>5)]   one float from the LDS image of W2^T ([k][i], conflict-free)
-//     B: lane l holds h1[row l&31][2s + (l>>5)]        computed once per coupling into 64 VGPRs
+//     B: lane l holds h1[row l&31][2s + (l>>5)]        one fma + max, made on the fly
 //     D: lane l holds, for ITS row (l&31), the 16 neurons i = 32t + (r&3) + 8(r>>2) + 4(l>>5), r = 0..15
 // i.e. the two lanes l and l+32 of a row each end up with half of the hidden units, reduce them against W3
 // in registers (64-term fmaf chains) and exchange the two partial sums with one ds_swizzle.  f32-input MFMA is
@@ -42,8 +42,9 @@ constexpr int NF_BLOCK_FLOATS = NF_B3_OFF + 4;                // = GLABC_NF_COUP
 static_assert(NF_BLOCK_FLOATS == GLABC_NF_COUPLING_FLOATS, "parameter block layout");
 
 constexpr int NF_WAVES = 4;
-constexpr int NF_TILES_PER_WAVE = 4;                          // 32-row tiles a wave pushes through per weight staging
-constexpr int NF_ROWS_PER_WG = 32 * NF_WAVES * NF_TILES_PER_WAVE;     // 512
+constexpr int NF_CUS = 256;
+// T = 32-row tiles a wave keeps in registers.  A launch is sized so that the grid is (a multiple of) the 256 CUs
+// and every workgroup stages each coupling's weights exactly once: rows per workgroup = 128 T.
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -60,37 +61,52 @@ struct NfArgs {
 };
 
 // (shift, log_s) of one coupling for this lane's row, conditioner input z0.  lds = staged parameter block.
+// k runs outermost: h1[k] is made on the fly (one fma + max) and feeds the four MFMAs of the four 32-neuron
+// output tiles, so the only live registers are the 4 x 16 accumulators.
 __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, float z0, int lane, float& shift, float& log_s)
 {
     const int half = lane >> 5, col = lane & 31;
-    // h1 for k = 2s + half, s = 0..63 (the B operand of every MFMA of this coupling)
-    float h1[64];
+    // the accumulators start at the bias b2: the pre-activation of hidden unit i is the k-ascending fmaf chain
+    //   fma(W2[i][127], h1[127], ... fma(W2[i][0], h1[0], b2[i]))
+    f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        acc0[r] = lds[NF_V4_OFF + 4 * i];
+        acc1[r] = lds[NF_V4_OFF + 4 * (i + 32)];
+        acc2[r] = lds[NF_V4_OFF + 4 * (i + 64)];
+        acc3[r] = lds[NF_V4_OFF + 4 * (i + 96)];
+    }
+    const float* w1 = lds + NF_W1_OFF + half;
+    const float* b1 = lds + NF_B1_OFF + half;
+    const float* wt = lds + NF_W2_OFF + half * NF_H + col;                // W2^T[2s + half][32t + col]
+    // (explicit operand prefetch rings were tried and measured no better than the compiler's schedule: the loop is
+    // limited by MFMA / VALU issue interleave, not LDS latency -- tools/ubench/mfma_f32.hip)
+#pragma unroll 8
     for (int s = 0; s < 64; ++s) {
-        const int k = 2 * s + half;
-        h1[s] = __builtin_fmaxf(__builtin_fmaf(lds[NF_W1_OFF + k], z0, lds[NF_B1_OFF + k]), 0.0f);
+        const float h1 = __builtin_fmaxf(__builtin_fmaf(w1[2 * s], z0, b1[2 * s]), 0.0f);
+        const float* row = wt + 2 * s * NF_H;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[0], h1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[32], h1, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[64], h1, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[96], h1, acc3, 0, 0, 0);
     }
     float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        const float* wt = lds + NF_W2_OFF + 32 * t + col;                 // W2^T[k][32t + col]
-#pragma unroll
-        for (int s = 0; s < 64; ++s) {
-            const float a = wt[(2 * s + half) * NF_H];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[s], acc, 0, 0, 0);
-        }
+    auto epilogue = [&](const f32x16& acc, int t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float4 v = *reinterpret_cast<const float4*>(lds + NF_V4_OFF + 4 * i);     // (b2, W3[0], W3[1], 0)
-            const float h2 = __builtin_fmaxf(acc[r] + v.x, 0.0f);
-            p0 = __builtin_fmaf(v.y, h2, p0);
-            p1 = __builtin_fmaf(v.z, h2, p1);
+            const float2 v = *reinterpret_cast<const float2*>(lds + NF_V4_OFF + 4 * i + 1);     // (W3[0][i], W3[1][i])
+            const float h2 = __builtin_fmaxf(acc[r], 0.0f);
+            p0 = __builtin_fmaf(v.x, h2, p0);
+            p1 = __builtin_fmaf(v.y, h2, p1);
         }
-    }
+        __builtin_amdgcn_sched_barrier(0);        // keep the next tile's LDS reads from being hoisted above (VGPR pressure)
+    };
+    epilogue(acc0, 0);
+    epilogue(acc1, 1);
+    epilogue(acc2, 2);
+    epilogue(acc3, 3);
     // partial sums of the two halves of the row: lane l <-> l + 32
     const float q0 = __shfl_xor(p0, 32, 64), q1 = __shfl_xor(p1, 32, 64);
     const float lo0 = half ? q0 : p0, hi0 = half ? p0 : q0;
@@ -99,9 +115,10 @@ __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, f
     log_s = (lo1 + hi1) + lds[NF_B3_OFF + 1];
 }
 
-template <bool INVERSE>
-__global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
+template <bool INVERSE, int NF_TILES_PER_WAVE>
+__global__ void __launch_bounds__(64 * NF_WAVES, 2) nf_kernel(const NfArgs a)
 {
+    constexpr int NF_ROWS_PER_WG = 32 * NF_WAVES * NF_TILES_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31;
@@ -220,19 +237,36 @@ static NfArgs nf_pack(const glabc_flow* f, const float* in, float* z, float* log
     return a;
 }
 
+template <bool INV, int T>
+static int nf_launch_t(const NfArgs& a, hipStream_t s)
+{
+    const size_t lds_bytes = sizeof(float) * NF_BLOCK_FLOATS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)nf_kernel<INV, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return GLABC_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int64_t rows_per_wg = 32 * NF_WAVES * T;
+    const unsigned grid = (unsigned)((a.n_rows + rows_per_wg - 1) / rows_per_wg);
+    hipLaunchKernelGGL((nf_kernel<INV, T>), dim3(grid), dim3(64 * NF_WAVES), lds_bytes, s, a);
+    return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
+}
+
+// tiles per wave: the smallest compiled T whose 256-workgroup grid (x2: two workgroups fit a CU) covers the rows,
+// so that the chip is filled evenly and each workgroup stages every coupling once
 template <bool INV>
 static int nf_launch(const NfArgs& a, hipStream_t s)
 {
-    const size_t lds_bytes = sizeof(float) * NF_BLOCK_FLOATS;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[INV]) {
-        if (hipFuncSetAttribute((const void*)nf_kernel<INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return GLABC_ERR_LAUNCH;
-        attr_set[INV] = true;
-    }
-    const unsigned grid = (unsigned)((a.n_rows + NF_ROWS_PER_WG - 1) / NF_ROWS_PER_WG);
-    hipLaunchKernelGGL((nf_kernel<INV>), dim3(grid), dim3(64 * NF_WAVES), lds_bytes, s, a);
-    return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
+    const int64_t per_t = (int64_t)2 * NF_CUS * NF_WAVES * 32;        // rows covered per unit of T
+    const int64_t need = (a.n_rows + per_t - 1) / per_t;
+    if (need <= 1) return nf_launch_t<INV, 1>(a, s);
+    if (need <= 2) return nf_launch_t<INV, 2>(a, s);
+    if (need <= 3) return nf_launch_t<INV, 3>(a, s);
+    if (need <= 4) return nf_launch_t<INV, 4>(a, s);
+    if (need <= 5) return nf_launch_t<INV, 5>(a, s);
+    if (need <= 6) return nf_launch_t<INV, 6>(a, s);
+    return nf_launch_t<INV, 8>(a, s);                                 // larger inputs: more workgroups of 1024 rows
 }
 
 extern "C" {

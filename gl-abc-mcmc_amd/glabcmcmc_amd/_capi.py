@@ -167,7 +167,8 @@ ENTRY_POINTS = {
 
 LIB_NAME = "libglabc_hip.so"
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "csrc", LIB_NAME)
+# GLABC_HIP_LIB: load another build of the same ABI (kernel experiments); default = the in-tree build
+LIB_PATH = os.environ.get("GLABC_HIP_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "csrc", LIB_NAME)
 
 _lib = None
 

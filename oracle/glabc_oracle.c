@@ -952,7 +952,7 @@ ORACLE_API int oracle_glmala_steps(const glabc_model* m, const glabc_dist* imp, 
 /* its published forward / inverse semantics are restated: this   */
 /* part of the oracle is NOT pinned by reference outputs ("parity unpinned").  */
 /* The arithmetic order is spelled out so that the matrix-core kernel can be   */
-/* checked bit for bit: the 128x128 layer is a k-ascending fmaf chain from 0   */
+/* checked bit for bit: the 128x128 layer is a k-ascending fmaf chain from b2  */
 /* (what v_mfma_f32_32x32x2_f32 computes), the 128->2 layer is two 64-term     */
 /* fmaf chains over the hidden units with bit 2 of their index clear / set, in */
 /* the order i = 32t + (r&3) + 8(r>>2) + 4h, t = 0..3, r = 0..15, then added.  */
@@ -971,10 +971,10 @@ static void nf_coupling_params(const float* blk, float z0, float* shift, float* 
         for (int t = 0; t < 4; ++t)
             for (int r = 0; r < 16; ++r) {
                 int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float acc = 0.0f;
-                for (int k = 0; k < NF_H; ++k) acc = __builtin_fmaf(blk[k * NF_H + i], h1[k], acc);      /* W2^T[k][i] */
                 const float* v = blk + NF_V4_OFF + 4 * i;                                                 /* (b2, W3[0], W3[1], 0) */
-                float h2 = fmaxf(acc + v[0], 0.0f);
+                float acc = v[0];                                                                         /* chain starts at b2 */
+                for (int k = 0; k < NF_H; ++k) acc = __builtin_fmaf(blk[k * NF_H + i], h1[k], acc);      /* W2^T[k][i] */
+                float h2 = fmaxf(acc, 0.0f);
                 part[h][0] = __builtin_fmaf(v[1], h2, part[h][0]);
                 part[h][1] = __builtin_fmaf(v[2], h2, part[h][1]);
             }
