@@ -222,6 +222,142 @@ __global__ void __launch_bounds__(256) sqrt_check_kernel(uint32_t first, uint32_
     }
     if (local) atomicAdd(bad, local);
 }
+
+// ---- GLMCMC_NF: pool weights and one iteration against the pool (GLMCMC_NFs.py:73-111,141-152) ---------------
+template <int D>
+struct PoolArgs {
+    StepArgs<D> s;
+    const float* theta;       // forward: [D][n] proposals ; step: pool theta
+    const float* x;
+    const float* w;
+    const float* log_q;
+    int32_t* kk;
+    float* x_out;
+    float* w_out;
+    int64_t n_rows, row_id0;
+    int32_t step_size;
+};
+
+template <int D>
+__global__ void __launch_bounds__(256) pool_weights_kernel(const PoolArgs<D> p)
+{
+    const StepArgs<D>& a = p.s;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= p.n_rows) return;
+    float th[D], y[D], eps[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) th[j] = p.theta[j * p.n_rows + r];
+    // simulator noise: D normals from Philox blocks (row id, 0, b), pairs (2i, 2i+1)
+    const uint64_t gid = (uint64_t)(p.row_id0 + r);
+    constexpr int NB = (D + 3) / 4;
+    float nrm[4 * NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, (uint32_t)b, a.seed_lo, a.seed_hi);
+        glabc_normal_pair(w.v[0], w.v[1], &nrm[4 * b], &nrm[4 * b + 1]);
+        glabc_normal_pair(w.v[2], w.v[3], &nrm[4 * b + 2], &nrm[4 * b + 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) eps[j] = nrm[j];
+    model_simulate<D>(a, th, eps, y);                                                   // GLMCMC_NFs.py:79
+    const float lw = (dist_log_prob<D>(a.prior, th) + model_log_kernel<D>(a, y)) - p.log_q[r];   // :80-81
+    const float v = glabc_expf(lw);                                                     // :82
+#pragma unroll
+    for (int j = 0; j < D; ++j) p.x_out[j * p.n_rows + r] = y[j];
+    p.w_out[r] = (v != v) ? 0.0f : v;                                                   // :83-85
+}
+
+template <int D, int N>
+__global__ void __launch_bounds__(64) nf_step_kernel(const PoolArgs<D> p)
+{
+    const StepArgs<D>& a = p.s;
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n_chains) return;
+    float th[D], y[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        th[j] = a.theta[j * a.stride + i];
+        y[j] = a.y[j * a.stride + i];
+    }
+    uint32_t n_moves = a.n_moves ? a.n_moves[i] : 0u;
+    int32_t kk = p.kk[i];
+    const uint64_t gid = (uint64_t)(a.chain0 + i);
+    Rng rng;
+    rng.c0 = (uint32_t)gid;
+    rng.c1 = (uint32_t)(gid >> 32);
+    rng.k0 = a.seed_lo;
+    rng.k1 = a.seed_hi;
+    const uint32_t step = a.step0;
+    glabc_u32x4 h = glabc_philox4x32_10(rng.c0, rng.c1, step, 0u, rng.k0, rng.k1);
+    const float prior_old = dist_log_prob<D>(a.prior, th), kern_old = model_log_kernel<D>(a, y);
+    bool moved = false;
+    if (glabc_uniform_f32(h.v[0]) < a.gf) {                                             // GLMCMC_NFs.py:91-92
+        float w[N + 1];
+        w[0] = glabc_expf((prior_old + kern_old) - p.log_q[i]);                         // :99-101 (NaN is NOT zeroed here)
+        const int64_t rows = (int64_t)p.step_size * N * a.n_chains;
+        const int64_t base = ((int64_t)kk * N) * a.n_chains + i;                        // row (kk*N + j)*C + c
+        const bool have = kk < p.step_size;
+#pragma unroll
+        for (int j = 0; j < N; ++j) w[j + 1] = have ? p.w[base + (int64_t)j * a.n_chains] : 0.0f;
+        const float tot = aten_rowsum<N + 1>(w);                                        // :103
+        const double u_res = glabc_uniform_f64(h.v[2], h.v[3]);
+        int ind = -1;
+        double run = 0.0;
+#pragma unroll
+        for (int k = 0; k <= N; ++k) {
+            run += (double)(w[k] / tot);
+            ind = (ind < 0 && u_res < run) ? k : ind;                                   // :104, :11-26
+        }
+        if (ind > 0 && have) {                                                          // :105-107
+            const int64_t r = base + (int64_t)(ind - 1) * a.n_chains;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                th[j] = p.theta[j * rows + r];
+                y[j] = p.x[j * rows + r];
+            }
+            moved = true;
+        }
+        kk += 1;                                                                        // :111
+    } else {                                                                            // :141-152
+        float e[D], s[D], tn[D], yn[D];
+        constexpr int SPP = (2 * D + 3) / 4;
+        uint32_t wd[4 * SPP];
+#pragma unroll
+        for (int b = 0; b < SPP; ++b) {
+            glabc_u32x4 o = glabc_philox4x32_10(rng.c0, rng.c1, step, (uint32_t)(1 + b), rng.k0, rng.k1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wd[4 * b + q] = o.v[q];
+        }
+        float nrm[2 * D];
+#pragma unroll
+        for (int q = 0; q < D; ++q) glabc_normal_pair(wd[2 * q], wd[2 * q + 1], &nrm[2 * q], &nrm[2 * q + 1]);
+        const bool uni = a.local.kind == GLABC_DIST_UNIFORM;
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+            e[q] = uni ? glabc_uniform_f32(wd[q]) : nrm[q];
+            s[q] = nrm[D + q];
+            tn[q] = (a.local.p0[q] + a.local.p2[q] * e[q]) + th[q];                     // :142
+        }
+        model_simulate<D>(a, tn, s, yn);
+        const float log_acc = ((dist_log_prob<D>(a.prior, tn) + model_log_kernel<D>(a, yn)) - prior_old) - kern_old;   // :145-146
+        if (glabc_logf(glabc_uniform_f32(h.v[1])) < log_acc) {                          // :147-148
+#pragma unroll
+            for (int q = 0; q < D; ++q) {
+                th[q] = tn[q];
+                y[q] = yn[q];
+            }
+            moved = true;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        a.theta[j * a.stride + i] = th[j];
+        a.y[j * a.stride + i] = y[j];
+        if (a.history) a.history[j * a.hist_stride + i] = th[j];
+    }
+    p.kk[i] = kk;
+    if (a.n_moves) a.n_moves[i] = n_moves + (moved ? 1u : 0u);
+}
 }  // namespace glabc
 
 // =================================================================================================
@@ -481,6 +617,94 @@ __attribute__((visibility("default"))) int glabc_glmala_init(const glabc_model* 
     }
     if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
     return rc;
+}
+
+}  // extern "C"
+
+template <int D>
+static int launch_pool_weights(const PoolArgs<D>& p, hipStream_t s)
+{
+    hipLaunchKernelGGL((pool_weights_kernel<D>), dim3(grid_for(p.n_rows, 256)), dim3(256), 0, s, p);
+    return finish_launch();
+}
+
+template <int D>
+static int launch_nf_step(const PoolArgs<D>& p, int N, hipStream_t s)
+{
+    dim3 grid(grid_for(p.s.n_chains, 64)), block(64);
+    switch (N) {
+#define GLABC_CASE(n) case n: hipLaunchKernelGGL((nf_step_kernel<D, n>), grid, block, 0, s, p); break;
+        GLABC_CASE(1) GLABC_CASE(2) GLABC_CASE(3) GLABC_CASE(4) GLABC_CASE(5) GLABC_CASE(6) GLABC_CASE(7) GLABC_CASE(8)
+        GLABC_CASE(9) GLABC_CASE(10) GLABC_CASE(11) GLABC_CASE(12) GLABC_CASE(13) GLABC_CASE(14) GLABC_CASE(15) GLABC_CASE(16)
+#undef GLABC_CASE
+    default: return GLABC_ERR_ARG;
+    }
+    return finish_launch();
+}
+
+extern "C" {
+
+__attribute__((visibility("default"))) int glabc_pool_weights(const glabc_model* model, const float* theta, const float* log_q,
+                                                              int64_t n_rows, uint64_t seed, int64_t row_id0, float* x_out,
+                                                              float* w_out, void* stream)
+{
+    int rc = check_model(model);
+    if (rc) return rc;
+    if (!theta || !log_q || !x_out || !w_out) return GLABC_ERR_NULL;
+    if (n_rows < 0 || row_id0 < 0) return GLABC_ERR_ARG;
+    if (n_rows == 0) return GLABC_OK;
+    glabc_chains dummy;
+    std::memset(&dummy, 0, sizeof dummy);
+    glabc_run r;
+    std::memset(&r, 0, sizeof r);
+    r.seed = seed;
+    hipStream_t s = (hipStream_t)stream;
+#define GLABC_POOLW(d)                                                        \
+    case d: {                                                                 \
+        PoolArgs<d> p;                                                        \
+        std::memset(&p, 0, sizeof p);                                         \
+        p.s = pack_args<d>(model, nullptr, &model->prior, &dummy, &r);        \
+        p.theta = theta; p.log_q = log_q; p.x_out = x_out; p.w_out = w_out;   \
+        p.n_rows = n_rows; p.row_id0 = row_id0;                               \
+        return launch_pool_weights<d>(p, s);                                  \
+    }
+    switch (model->theta_dim) {
+        GLABC_POOLW(1) GLABC_POOLW(2) GLABC_POOLW(3) GLABC_POOLW(4)
+    default: return GLABC_ERR_DIM;
+    }
+#undef GLABC_POOLW
+}
+
+__attribute__((visibility("default"))) int glabc_glmcmc_nf_step(const glabc_model* model, const glabc_dist* local,
+                                                                const glabc_pool* pool, const glabc_chains* c,
+                                                                const glabc_run* r, void* stream)
+{
+    int rc = check_model(model);
+    if (rc) return rc;
+    rc = check_dist(local, model->theta_dim);
+    if (rc) return rc;
+    if (!pool || !c || !r) return GLABC_ERR_NULL;
+    if (!pool->theta || !pool->x || !pool->w || !pool->log_q_old || !pool->kk || !c->theta || !c->y) return GLABC_ERR_NULL;
+    if (c->n_chains < 0 || c->stride < c->n_chains || c->chain0 < 0 || pool->step_size < 1) return GLABC_ERR_ARG;
+    if (r->n_steps != 1 || r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH) return GLABC_ERR_ARG;
+    if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
+    if (r->tape || r->moments) return GLABC_ERR_ARG;
+    if (c->n_chains == 0) return GLABC_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define GLABC_NFSTEP(d)                                                       \
+    case d: {                                                                 \
+        PoolArgs<d> p;                                                        \
+        std::memset(&p, 0, sizeof p);                                         \
+        p.s = pack_args<d>(model, local, &model->prior, c, r);                \
+        p.theta = pool->theta; p.x = pool->x; p.w = pool->w; p.log_q = pool->log_q_old; p.kk = pool->kk; \
+        p.step_size = pool->step_size;                                        \
+        return launch_nf_step<d>(p, r->batch_size, s);                        \
+    }
+    switch (model->theta_dim) {
+        GLABC_NFSTEP(1) GLABC_NFSTEP(2) GLABC_NFSTEP(3) GLABC_NFSTEP(4)
+    default: return GLABC_ERR_DIM;
+    }
+#undef GLABC_NFSTEP
 }
 
 }  // extern "C"

@@ -1,7 +1,107 @@
-"""GLMCMC_NF -- normalizing-flow global proposal (reference: GLMCMC_NFs.py:43-186).
-The RealNVP coupling kernels (MFMA) are not built yet."""
+"""GLMCMC_NF -- iSIR against a pool of normalizing-flow proposals + random-walk MH local move
+(reference: GLMCMC_NFs.py:43-186).
+
+Same positional signature as the reference function (``base`` is accepted for signature parity; pass a
+``flows.BaseDiagGaussian`` or None -- the reference passes ``nf.distributions.base.DiagGaussian(2)``).  The flow is
+``flows.RealNVP`` (the restatement of the normflows model the reference builds, GLMCMC_NFs.py:51-61):
+
+* pool draw  ``NF_model.sample(batch_size*step_size)`` per chain  -> ``glabc_nf_sample`` (f32 MFMA), GLMCMC_NFs.py:70-72
+* pool weights (simulate, prior, kernel, exp)                     -> ``glabc_pool_weights``,        :73-85
+* per iteration: ``NF_model.log_prob(Theta_old)``                  -> ``glabc_nf_log_prob`` (f32 MFMA), :96-98
+                 iSIR against the next pool slice / RW-MH          -> ``glabc_glmcmc_nf_step``,        :92-111,141-152
+* when a pool is used up: at most ``Train_step`` Adam steps on the forward KL of a systematically resampled pool
+  (:112-124, ``resample`` :29-40) -- stock PyTorch autograd on the same device -- then a new pool (:125-140).
+
+Batched use (``Initial_theta`` of shape (C, d)): all chains share ONE flow; every chain owns a pool; pools are
+redrawn together as soon as one chain has used its ``step_size`` slices.  With C = 1 this is the reference's schedule.
+Keyword-only extras: ``num_layers`` (reference: 32, GLMCMC_NFs.py:51), ``seed``, ``device``, ``chain0``,
+``return_device``, ``verbose``, ``flow`` (reuse / inspect the model), ``lr`` / ``weight_decay`` (:63).
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi, _host, engine
+from .flows import RealNVP
+
+
+def resample(W, N):
+    """Systematic resampling (GLMCMC_NFs.py:29-40): counts of u_i = (u + i)/N below each cumulative weight."""
+    u = (torch.rand(1, device=W.device) + torch.arange(N, device=W.device)) / N
+    Psum = torch.cumsum(W, dim=0)
+    idx = torch.searchsorted(Psum, u, right=True)               # u_i < Psum[j]  <=>  index j gets u_i
+    return idx.clamp_(max=W.numel() - 1)
 
 
 def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
-              filelocation, global_frequency, step_size, batch_size, base, Train_step, **kw):
-    raise NotImplementedError("GLMCMC_NF: HIP coupling kernels not implemented yet (no CPU fallback by design)")
+              filelocation, global_frequency, step_size, batch_size, base, Train_step, *,
+              num_layers=32, seed=None, device=None, chain0=0, return_device=False, verbose=True, flow=None,
+              lr=5e-4, weight_decay=1e-5, state_out=None):
+    lib = _capi.lib()
+    model = engine.model_descriptor(ABCset)
+    local = Local_Proposal.descriptor()
+    dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
+    if chains.d != 2:
+        raise ValueError("the RealNVP of GLMCMC_NF is built for theta_dim = 2 (MLP([1,128,128,2]), GLMCMC_NFs.py:56)")
+    n, N, P = chains.n, int(batch_size), int(batch_size) * int(step_size)
+    key = engine.draw_seed(seed)
+    if flow is None:
+        flow = RealNVP(num_layers, base if isinstance(base, torch.nn.Module) else None)
+    flow = flow.to(dev)
+    optimizer = torch.optim.Adam(flow.parameters(), lr=lr, weight_decay=weight_decay)            # :63
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    hist = _host.allocate_history(num_ite, chains, True)
+    kk = torch.zeros(n, dtype=torch.int32, device=dev)
+    pool = {}
+    losses = []
+
+    def draw_pool(refresh_id):
+        rows = P * n
+        flow.eval()
+        z, lq = flow.sample(rows, seed=key ^ 0x9E3779B97F4A7C15, row0=refresh_id * rows)        # row r = p*n + c
+        theta = z.t().contiguous()                                                                 # [2][rows]
+        x = torch.empty(chains.yd, rows, dtype=torch.float32, device=dev)
+        w = torch.empty(rows, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _capi.check(lib.glabc_pool_weights(C.byref(model), theta.data_ptr(), lq.data_ptr(), rows, key ^ 0x5851F42D4C957F2D,
+                                               refresh_id * rows, x.data_ptr(), w.data_ptr(), stream), "glabc_pool_weights")
+        pool.update(theta=theta, x=x, w=w, lq=lq)
+        kk.zero_()
+
+    refresh, num_train = 0, 0
+    draw_pool(refresh)
+    log_q_old = torch.empty(n, dtype=torch.float32, device=dev)
+    for i in range(1, num_ite):
+        blob = flow.packed_params()
+        fdesc = flow.descriptor(blob)
+        with torch.cuda.device(dev):
+            _capi.check(lib.glabc_nf_log_prob(C.byref(fdesc), chains.theta.data_ptr(), n, log_q_old.data_ptr(), stream),
+                        "glabc_nf_log_prob")                                                       # :96-98
+            pd = _capi.Pool(pool["theta"].data_ptr(), pool["x"].data_ptr(), pool["w"].data_ptr(), log_q_old.data_ptr(),
+                            kk.data_ptr(), int(step_size), 0)
+            cs = chains.struct()
+            run = _capi.Run()
+            run.seed, run.step0, run.n_steps = key, i, 1
+            run.global_frequency, run.batch_size = float(global_frequency), N
+            run.history, run.hist_stride = hist[i].data_ptr(), n
+            _capi.check(lib.glabc_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pd), C.byref(cs), C.byref(run),
+                                                 stream), "glabc_glmcmc_nf_step")
+        if int(kk.max().item()) >= int(step_size):                                                 # :112
+            if num_train < Train_step:                                                             # :114-124
+                flow.train()
+                optimizer.zero_grad()
+                w = pool["w"]
+                Train_weight = w / torch.sum(w)
+                idx = resample(Train_weight, w.numel())
+                Train_t = pool["theta"].t()[idx].detach().float()
+                loss = flow.forward_kld(Train_t)
+                if not (torch.isnan(loss) | torch.isinf(loss)):
+                    loss.backward()
+                optimizer.step()                                                                   # (B11: steps even when backward was skipped)
+                num_train += 1
+                losses.append(float(loss.detach()))
+            refresh += 1
+            draw_pool(refresh)                                                                     # :125-140
+    if state_out is not None:
+        state_out.update(chains=chains, flow=flow, loss_hist=losses, num_train=num_train)
+    return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)

@@ -104,6 +104,19 @@ class Flow(C.Structure):
     ]
 
 
+class Pool(C.Structure):
+    """struct glabc_pool"""
+    _fields_ = [
+        ("theta", C.c_void_p),
+        ("x", C.c_void_p),
+        ("w", C.c_void_p),
+        ("log_q_old", C.c_void_p),
+        ("kk", C.c_void_p),
+        ("step_size", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 class Moments(C.Structure):
     """struct glabc_moments"""
     _fields_ = [
@@ -151,6 +164,9 @@ ENTRY_POINTS = {
     "glabc_glmala_init": (C.c_int, [_P(Model), _P(Chains), C.c_void_p]),
     "glabc_nf_sample": (C.c_int, [_P(Flow), C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "glabc_nf_log_prob": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_pool_weights": (C.c_int, [_P(Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "glabc_glmcmc_nf_step": (C.c_int, [_P(Model), _P(Dist), _P(Pool), _P(Chains), _P(Run), C.c_void_p]),
     "glabc_init_weights": (C.c_int, [_P(Model), _P(Dist), _P(Chains), C.c_void_p]),
     "glabc_dist_log_prob": (C.c_int, [_P(Dist), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_prior_log_prob": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -219,6 +219,33 @@ int glabc_nf_sample(const glabc_flow* flow, const float* eps, uint64_t seed, int
 /* NF_model.log_prob(x): x pulled back through the couplings in reverse order (inverse pass) + base log_prob. */
 int glabc_nf_log_prob(const glabc_flow* flow, const float* x, int64_t n_rows, float* log_q, void* stream);
 
+/* ---- GLMCMC_NF (GLMCMC_NFs.py:43-186): iSIR against a pool of flow proposals -----------------------------
+ * A pool holds P = batch_size*step_size proposals per chain, row r = p*n_chains + c (slice kk of chain c =
+ * rows p in [kk*batch_size, (kk+1)*batch_size)), arrays chain-major [dim][P*n_chains].
+ *
+ * glabc_pool_weights, GLMCMC_NFs.py:73-85 / 128-140: x = generate_samples(theta) with Philox noise keyed by
+ * (row_id0 + r), w = exp(prior(theta) + K(x) - log_q), NaN -> 0. */
+int glabc_pool_weights(const glabc_model* model, const float* theta, const float* log_q, int64_t n_rows,
+                       uint64_t seed, int64_t row_id0, float* x_out, float* w_out, void* stream);
+
+/* One iteration (GLMCMC_NFs.py:90-111,141-152) for every chain: with probability global_frequency the iSIR
+ * move against the chain's next pool slice -- weights cat(exp(prior + K - log_q_old), pool_w[slice]) normalised
+ * with torch.sum, index by the double running sum (GLMCMC_NFs.py:11-26), kk += 1 -- else the random-walk MH
+ * local move (same draws as glabc_glmcmc_steps).  log_q_old[c] = NF_model.log_prob(Theta_old) (glabc_nf_log_prob
+ * on chains->theta).  run->n_steps must be 1; run->history (if any) receives the row. */
+typedef struct glabc_pool {
+    const float* theta;            /* [theta_dim][P*n_chains] */
+    const float* x;                /* [y_dim][P*n_chains] */
+    const float* w;                /* [P*n_chains] */
+    const float* log_q_old;        /* [n_chains] */
+    int32_t* kk;                   /* [n_chains] slices already consumed, GLMCMC_NFs.py:86,111 */
+    int32_t step_size;             /* slices per pool */
+    int32_t reserved;
+} glabc_pool;
+
+int glabc_glmcmc_nf_step(const glabc_model* model, const glabc_dist* local, const glabc_pool* pool,
+                         const glabc_chains* chains, const glabc_run* run, void* stream);
+
 /* GLMCMC.py:52-55 -- (re)initialise log_w = prior + log-kernel - q(theta) and set
  * GLABC_FLAG_LOCAL for every chain. */
 int glabc_init_weights(const glabc_model* model, const glabc_dist* importance,

@@ -1037,6 +1037,86 @@ ORACLE_API int oracle_nf_log_prob(const glabc_flow* f, const float* x, int64_t n
     return 0;
 }
 
+
+/* ---- GLMCMC_NF pool weights and one iteration against the pool (GLMCMC_NFs.py:73-111,141-152) ---- */
+ORACLE_API int oracle_pool_weights(const glabc_model* m, const float* theta, const float* log_q, int64_t n, uint64_t seed,
+                                   int64_t row_id0, float* x_out, float* w_out)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    int d = m->theta_dim;
+    for (int64_t r = 0; r < n; ++r) {
+        float th[GLABC_MAX_DIM], y[GLABC_MAX_DIM], eps[GLABC_MAX_DIM + 4];
+        for (int j = 0; j < d; ++j) th[j] = theta[j * n + r];
+        uint64_t gid = (uint64_t)(row_id0 + r);
+        for (int b = 0; b < (d + 3) / 4; ++b) {
+            glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, (uint32_t)b, (uint32_t)seed,
+                                                (uint32_t)(seed >> 32));
+            glabc_normal_pair(w.v[0], w.v[1], &eps[4 * b], &eps[4 * b + 1]);
+            glabc_normal_pair(w.v[2], w.v[3], &eps[4 * b + 2], &eps[4 * b + 3]);
+        }
+        model_simulate(m, th, eps, y);                                                      /* :79 */
+        float lw = (model_prior(m, th) + model_log_kernel(m, y)) - log_q[r];                /* :80-81 */
+        float v = glabc_expf(lw);                                                           /* :82 */
+        for (int j = 0; j < d; ++j) x_out[j * n + r] = y[j];
+        w_out[r] = isnan(v) ? 0.0f : v;                                                     /* :83-85 */
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_glmcmc_nf_step(const glabc_model* m, const glabc_dist* local, const glabc_pool* pool,
+                                     const glabc_chains* c, const glabc_run* run)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    if (!local || !pool || !c || !run) return GLABC_ERR_NULL;
+    if (run->n_steps != 1) return GLABC_ERR_ARG;
+    int d = m->theta_dim, yd = m->y_dim, N = run->batch_size;
+    int64_t C = c->n_chains, rows = (int64_t)pool->step_size * N * C;
+    for (int64_t i = 0; i < C; ++i) {
+        chain_state s;
+        step_draws dr;
+        memset(&dr, 0, sizeof dr);
+        load_chain(&s, c, i, d, yd);
+        draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0, 1, d, yd, 0);
+        int kk = pool->kk[i], moved = 0;
+        if (dr.u_branch < run->global_frequency) {                                          /* :91-92 */
+            float w[GLABC_MAX_BATCH + 1];
+            w[0] = glabc_expf((model_prior(m, s.theta) + model_log_kernel(m, s.y)) - pool->log_q_old[i]);   /* :99-101 */
+            int have = kk < pool->step_size;
+            int64_t base = ((int64_t)kk * N) * C + i;
+            for (int j = 0; j < N; ++j) w[j + 1] = have ? pool->w[base + (int64_t)j * C] : 0.0f;
+            float tot = aten_rowsum_f32(w, N + 1);                                          /* :103 */
+            int ind = -1;
+            double acc = 0.0;
+            for (int k = 0; k <= N; ++k) {
+                acc += (double)(w[k] / tot);
+                if (dr.u_resample < acc) { ind = k; break; }                                /* :104 */
+            }
+            if (ind > 0 && have) {                                                          /* :105-107 */
+                int64_t r = base + (int64_t)(ind - 1) * C;
+                for (int j = 0; j < d; ++j) s.theta[j] = pool->theta[j * rows + r];
+                for (int j = 0; j < yd; ++j) s.y[j] = pool->x[j * rows + r];
+                moved = 1;
+            }
+            kk += 1;                                                                        /* :111 */
+        } else {
+            if (local->kind == GLABC_DIST_UNIFORM)
+                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0, 1, d, yd, 1);
+            moved = local_move(m, local, &s, &dr);                                          /* :141-152 */
+        }
+        s.n_moves += (uint32_t)moved;
+        for (int j = 0; j < d; ++j) {
+            c->theta[j * c->stride + i] = s.theta[j];
+            if (run->history) run->history[j * run->hist_stride + i] = s.theta[j];
+        }
+        for (int j = 0; j < yd; ++j) c->y[j * c->stride + i] = s.y[j];
+        if (c->n_moves) c->n_moves[i] = s.n_moves;
+        pool->kk[i] = kk;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* ESJD.py:2-25 : det( D^T D / (n-1) )^(1/d), D = consecutive differences, all float32.
  * torch.det is an LU with partial pivoting; restated for d <= GLABC_MAX_DIM.

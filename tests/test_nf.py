@@ -109,3 +109,80 @@ def test_full_size_invertibility(hip):
     with torch.no_grad():
         lpt = flow.log_prob_torch(z[:20000])
     assert (lpt - lp[:20000]).abs().max().item() < 2e-4
+
+
+def _mix_descs(eps=0.3):
+    from helpers import descriptors
+    return descriptors(dict(epsilon=eps, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])}))
+
+
+@pytest.mark.gpu
+def test_pool_weights_and_nf_step_equal_oracle(hip, oracle):
+    """glabc_pool_weights and glabc_glmcmc_nf_step (GLMCMC_NFs.py:73-111,141-152) against the oracle, bit for bit."""
+    import oracle_lib
+    model, local, _ = _mix_descs()
+    rng = np.random.default_rng(0)
+    n_chains, N, step_size = 300, 5, 3
+    P = N * step_size
+    rows = P * n_chains
+    theta = (rng.standard_normal((2, rows)) * 1.5).astype(np.float32)
+    log_q = (rng.standard_normal(rows) - 3).astype(np.float32)
+    x = np.empty((2, rows), np.float32)
+    w = np.empty(rows, np.float32)
+    assert oracle.oracle_pool_weights(C.byref(model), theta.ctypes.data, log_q.ctypes.data, rows, 11, 1 << 35, x.ctypes.data,
+                                      w.ctypes.data) == 0
+    tg, lg = torch.from_numpy(theta).cuda(), torch.from_numpy(log_q).cuda()
+    xg, wg = torch.empty(2, rows, device="cuda"), torch.empty(rows, device="cuda")
+    assert hip.glabc_pool_weights(C.byref(model), tg.data_ptr(), lg.data_ptr(), rows, 11, 1 << 35, xg.data_ptr(), wg.data_ptr(),
+                                  None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(xg.cpu().numpy()), bits(x)) and np.array_equal(bits(wg.cpu().numpy()), bits(w))
+    assert (w > 0).any()
+    # iterations against the pool (more global steps than slices: the exhausted-pool guard is exercised too)
+    theta0 = rng.standard_normal((n_chains, 2)).astype(np.float32)
+    y0 = np.abs(theta0).astype(np.float32)
+    hc = oracle_lib.HostChains(theta0, y0, chain0=7, with_isir=False)
+    kk_h = np.zeros(n_chains, np.int32)
+    from glabcmcmc_amd import engine
+    gc = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), torch.device("cuda", 0), chain0=7)
+    kk_g = torch.zeros(n_chains, dtype=torch.int32, device="cuda")
+    for it in range(1, 8):
+        lqo = (rng.standard_normal(n_chains) - 2).astype(np.float32)
+        hrow = np.zeros((2, n_chains), np.float32)
+        pool_h = A.Pool(theta.ctypes.data, x.ctypes.data, w.ctypes.data, lqo.ctypes.data, kk_h.ctypes.data, step_size, 0)
+        run_h, keep = oracle_lib.make_run(seed=5, step0=it, n_steps=1, gf=0.7, batch=N, history=hrow)
+        cs = hc.struct()
+        assert oracle.oracle_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pool_h), C.byref(cs), C.byref(run_h)) == 0
+        lg2 = torch.from_numpy(lqo).cuda()
+        hg = torch.empty(2, n_chains, device="cuda")
+        pool_g = A.Pool(tg.data_ptr(), xg.data_ptr(), wg.data_ptr(), lg2.data_ptr(), kk_g.data_ptr(), step_size, 0)
+        run_g = A.Run()
+        run_g.seed, run_g.step0, run_g.n_steps, run_g.global_frequency, run_g.batch_size = 5, it, 1, 0.7, N
+        run_g.history, run_g.hist_stride = hg.data_ptr(), n_chains
+        csg = gc.struct()
+        assert hip.glabc_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pool_g), C.byref(csg), C.byref(run_g), None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(hg.cpu().numpy()), bits(hrow)), it
+        assert np.array_equal(kk_g.cpu().numpy(), kk_h)
+        assert np.array_equal(bits(gc.y.cpu().numpy()), bits(hc.y))
+    assert hc.n_moves.sum() > 0 and np.array_equal(gc.n_moves.cpu().numpy().astype(np.uint32), hc.n_moves)
+
+
+@pytest.mark.gpu
+def test_glmcmc_nf_end_to_end(hip):
+    """GLMCMC_NF on the GPU: shapes of the reference API, the flow trains (forward-KL drops), chains reach the posterior."""
+    import glabcmcmc_amd as g
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    m = Mixture_set(0.3)
+    lp = g.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35])))
+    st = {}
+    out = g.GLMCMC_NF(m, 120, torch.zeros(256, 2), torch.full((256, 2), 1.5), lp, None, 0.7, 4, 5, None, 10,
+                      num_layers=4, seed=1, state_out=st, lr=5e-3)
+    assert out.shape == (120, 256, 2) and torch.isfinite(out).all()
+    assert st["num_train"] >= 5 and np.isfinite(st["loss_hist"]).all()
+    assert st["loss_hist"][-1] < st["loss_hist"][0]                      # the proposal moves toward the weighted pool
+    late = out[60:].abs().mean().item()
+    assert 1.0 < late < 1.9                                              # |theta| near 1.4-1.5 (prior gives 0.8)
+    one = g.GLMCMC_NF(m, 30, torch.tensor([0.0, 0.0]), torch.tensor([[1.5, 1.5]]), lp, None, 0.5, 3, 5, None, 2,
+                      num_layers=2, seed=2, verbose=False)
+    assert one.shape == (30, 2) and one.device.type == "cpu"
