@@ -35,9 +35,15 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290
 EPS, GF, NBATCH, D = 0.05, 0.9, 5, 2
 
 
-def descriptors():
+def descriptors(workload="glmcmc"):
     from glabcmcmc_amd import distribution
     from glabcmcmc_amd.examples.Mixture import Mixture_set
+    if workload == "gk":            # BASELINE configs[3]: g-and-k, theta_dim 4, Uniform(0,10)^4 prior and importance proposal
+        from glabcmcmc_amd.examples.GK import GK_set
+        model = GK_set(0.6).descriptor()
+        lp = distribution.DiagGaussian(4, torch.zeros(1, 4), torch.log(torch.tensor([0.15, 0.1, 0.2, 0.1]))).descriptor()
+        ip = distribution.Uniform(4, torch.zeros(4), torch.full((4,), 10.0)).descriptor()
+        return model, lp, ip
     model = Mixture_set(EPS).descriptor()
     lp = distribution.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35]))).descriptor()
     ip = distribution.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0])).descriptor()
@@ -139,7 +145,7 @@ def main():
     ap.add_argument("--no-history", action="store_true", help="diagnostic: do not write Theta_Re rows")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default; geometry only)")
     ap.add_argument("--couplings", type=int, default=8, help="nf workload: number of couplings")
-    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf"],
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
@@ -160,24 +166,31 @@ def main():
 
     from glabcmcmc_amd import engine
     from glabcmcmc_amd.parallel import gather_chain_stats
-    model, lp, ip = descriptors()
+    model, lp, ip = descriptors(args.workload)
+    Dw = 4 if args.workload == "gk" else D
     n, K = args.chains, args.iters
     seed = 20261003
 
     # synthetic inputs, resident in HBM before the timed region: theta0 = 0 for every chain,
     # y0 = |theta0| + sqrt(0.05) z  
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    theta0 = torch.zeros(n, D)
-    y0 = (0.05 ** 0.5) * torch.randn(n, D, generator=g)
+    if args.workload == "gk":
+        from glabcmcmc_amd.examples.GK import GK_set
+        theta0 = torch.rand(n, 4, generator=g) * 10
+        torch.manual_seed(1234 + rank)
+        y0 = GK_set(0.6).generate_samples(theta0)
+    else:
+        theta0 = torch.zeros(n, D)
+        y0 = (0.05 ** 0.5) * torch.randn(n, D, generator=g)
     chains = engine.ChainBatch(theta0, y0, dev, chain0=rank * n)
     engine.init_weights(model, ip, chains)
-    hist = None if args.no_history else torch.empty(K, D, n, dtype=torch.float32, device=dev)
-    mom = engine.Moments(n, D, dev)
+    hist = None if args.no_history else torch.empty(K, Dw, n, dtype=torch.float32, device=dev)
+    mom = engine.Moments(n, Dw, dev)
 
     step_idx = [0]
 
     from glabcmcmc_amd import _capi
-    gf = {"glmcmc": GF, "globalmcmc": 0.5, "glmala": 0.8}[args.workload]
+    gf = {"glmcmc": GF, "globalmcmc": 0.5, "glmala": 0.8, "gk": 0.9}[args.workload]
     mala = _capi.Mala(0.3, 0.3 ** 2, EPS ** 2, 100, 0)                  # README.md:128
     if args.workload == "glmala":
         chains.add_mala_state()
@@ -188,7 +201,7 @@ def main():
             engine.run_glmala_steps(model, ip, mala, chains, K, 1 + step_idx[0] * K, seed, gf, NBATCH, history=hist,
                                     moments=mom, steps_per_launch=K)
         else:
-            entry = "glabc_glmcmc_steps" if args.workload == "glmcmc" else "glabc_globalmcmc_steps"
+            entry = "glabc_globalmcmc_steps" if args.workload == "globalmcmc" else "glabc_glmcmc_steps"
             engine.run_steps(entry, model, lp, ip, chains, K, 1 + step_idx[0] * K, seed, gf, NBATCH,
                              history=hist, moments=mom, steps_per_launch=K, lanes_per_chain=args.lanes)
         step_idx[0] += 1
@@ -221,10 +234,11 @@ def main():
 
     if rank == 0:
         # algorithmic HBM bytes of one launch: state in + out, history rows, moment sums in + out
-        S = D + D + 1 + 2                                  # theta, y, log_w, flags, n_moves  (4-byte words)
-        tri = D * (D + 1) // 2
-        state_bytes = 2 * 4 * S * n + 2 * 8 * (D + 2 * tri) * n
-        hist_bytes = 0 if args.no_history else 4 * D * n * K
+        Dy = 8 if args.workload == "gk" else D
+        S = Dw + Dy + 1 + 2                                # theta, y, log_w, flags, n_moves  (4-byte words)
+        tri = Dw * (Dw + 1) // 2
+        state_bytes = 2 * 4 * S * n + 2 * 8 * (Dw + 2 * tri) * n
+        hist_bytes = 0 if args.no_history else 4 * Dw * n * K
         algo_bytes = state_bytes + hist_bytes
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         steps_all = mom.steps
@@ -253,19 +267,22 @@ def main():
             "config": {"workload": {"glmcmc": "GLMCMC iSIR N=5 gf=0.9, Mixture_set eps=0.05 d=2 (BASELINE configs[1])",
                                     "globalmcmc": "GlobalMCMC gf=0.5, Mixture_set eps=0.05 d=2 (BASELINE configs[0], batched)",
                                     "glmala": "GLMALA iSIR N=5 gf=0.8 tau=0.3 num_grad=100, Mixture_set eps=0.05 d=2 "
-                                              "(BASELINE configs[2])"}[args.workload],
+                                              "(BASELINE configs[2])",
+                                    "gk": "GLMCMC iSIR N=5 gf=0.9 on the g-and-k model (theta_dim 4, y_dim 8, eps 0.6), "
+                                          "chains sharded over the GPUs (BASELINE configs[3])"}[args.workload],
                        "chains_per_gpu": n, "iters_per_step": K, "batch_size": NBATCH, "history": not args.no_history,
                        "lanes_per_chain": args.lanes or "auto",
                        "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "esjd_mean": float(esjd_all[ok].double().mean()), "esjd_nan_frac": float(1.0 - ok.double().mean()),
             "mean_theta": stats["mean"], "mean_theta_sq": stats["mean_sq"],
-            "analytic": {"mean_theta": 0.0, "mean_theta_sq": 2.081014},
+            "analytic": {"mean_theta": 0.0, "mean_theta_sq": 2.081014} if args.workload != "gk" else None,
             "moment_iters": steps_all,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {"glmcmc": "glabc::sampler_kernel<GLMCMC, D=2, N=5>",
                                     "globalmcmc": "glabc::sampler_kernel<GLOBAL, D=2, N=1>",
-                                    "glmala": "glabc::glmala_kernel<D=2, N=5>"}[args.workload], "kernel_ms": kernel_ms,
+                                    "glmala": "glabc::glmala_kernel<D=2, N=5>",
+                                    "gk": "glabc::sampler_kernel<GLMCMC, D=4, YD=8, N=5>"}[args.workload], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_chain_step": algo_bytes / (n * K),
                          "valu": valu,

@@ -56,12 +56,15 @@ struct DistArgs {
     float p0[D], p1[D], p2[D];
 };
 
-template <int D>
+template <int D, int YD = D>
 struct StepArgs {
-    // Model callbacks (examples/Mixture.py:13-45); y_dim == theta_dim for |theta| + noise
+    // Model callbacks (examples/Mixture.py:13-45).  sim_kind GLABC_SIM_ABS_GAUSS: y = |theta| + noise (y_dim == theta_dim);
+    // GLABC_SIM_GK: y = sorted g-and-k variates (theta = (A, B, g, k), examples/GK.py)
     DistArgs<D> prior;
-    float noise_loc[D], noise_scale[D];
-    float y_obs[D];
+    int32_t sim_kind;
+    float gk_c;
+    float noise_loc[YD], noise_scale[YD];
+    float y_obs[YD];
     float kern_log_scale, kern_scale, kern_c0;
     // proposals: local increment (GLMCMC.py:91) and global / importance (GLMCMC.py:66, GlobalMCMC.py:40)
     DistArgs<D> local, global;
@@ -179,29 +182,69 @@ GLABC_DEV float dist_forward_log_p(const DistArgs<D>& g, const float (&noise)[D]
     return g.c0;
 }
 
-// ---- examples/Mixture.py ----------------------------------------------------------------
-// generate_samples, Mixture.py:19-23: y = |theta| + (loc + scale*eps)
-template <int D>
-GLABC_DEV void model_simulate(const StepArgs<D>& a, const float (&theta)[D], const float (&eps)[D], float (&y)[D])
+// ---- the Model callbacks ---------------------------------------------------------------------
+// tanh and x^k for the g-and-k quantile function, spelled with the specified exp / log
+GLABC_DEV float gk_tanhf(float x)
+{
+    const float e = glabc_expf(-2.0f * __builtin_fabsf(x));
+    const float r = (1.0f - e) / (1.0f + e);
+    return x < 0.0f ? -r : r;
+}
+
+// ascending sort of N registers (compare-exchange network; odd-even transposition for small N)
+template <int N>
+GLABC_DEV void sort_ascending(float (&v)[N])
 {
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        float noise = a.noise_loc[j] + a.noise_scale[j] * eps[j];
-        y[j] = __builtin_fabsf(theta[j]) + noise;
+    for (int pass = 0; pass < N; ++pass) {
+#pragma unroll
+        for (int i = pass & 1; i + 1 < N; i += 2) {
+            const float lo = __builtin_fminf(v[i], v[i + 1]), hi = __builtin_fmaxf(v[i], v[i + 1]);
+            v[i] = lo;
+            v[i + 1] = hi;
+        }
+    }
+}
+
+// generate_samples for one theta and one simulation.
+//   ABS_GAUSS, examples/Mixture.py:19-23:  y = |theta| + (loc + scale*eps)
+//   GK, examples/GK.py:  y_j = A + B (1 + c tanh(g z_j / 2)) (1 + z_j^2)^k z_j, then sorted (order statistics)
+template <int D, int YD>
+GLABC_DEV void model_simulate(const StepArgs<D, YD>& a, const float (&theta)[D], const float (&eps)[YD], float (&y)[YD])
+{
+    if constexpr (YD == D) {
+        if (a.sim_kind == GLABC_SIM_ABS_GAUSS) {
+#pragma unroll
+            for (int j = 0; j < YD; ++j) {
+                float noise = a.noise_loc[j] + a.noise_scale[j] * eps[j];
+                y[j] = __builtin_fabsf(theta[j]) + noise;
+            }
+            return;
+        }
+    }
+    if constexpr (D >= 4) {
+#pragma unroll
+        for (int j = 0; j < YD; ++j) {
+            const float z = eps[j];
+            const float t = gk_tanhf((theta[2] * z) * 0.5f);
+            const float pw = glabc_expf(theta[3] * glabc_logf(1.0f + z * z));
+            y[j] = theta[0] + ((theta[1] * (1.0f + a.gk_c * t)) * pw) * z;
+        }
+        sort_ascending<YD>(y);
     }
 }
 
 // calculate_log_kernel, Mixture.py:33-45: DiagGaussian(1, 0, log eps).log_prob(||y - y_obs||)
-template <int D>
-GLABC_DEV float model_log_kernel(const StepArgs<D>& a, const float (&y)[D])
+template <int D, int YD>
+GLABC_DEV float model_log_kernel(const StepArgs<D, YD>& a, const float (&y)[YD])
 {
-    float t[D];
+    float t[YD];
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
+    for (int j = 0; j < YD; ++j) {
         float d = y[j] - a.y_obs[j];
         t[j] = d * d;
     }
-    float dis = __builtin_sqrtf(aten_rowsum<D>(t));
+    float dis = __builtin_sqrtf(aten_rowsum<YD>(t));
     float e = (dis - 0.0f) / a.kern_scale;
     return a.kern_c0 - (a.kern_log_scale + 0.5f * (e * e));
 }
@@ -266,10 +309,10 @@ GLABC_DEV void gather_weights(const float (&wl)[NL], float (&w)[N + 1])
 }
 
 // ---- chain state in registers ---------------------------------------------------------
-template <int D>
+template <int D, int YD = D>
 struct Chain {
     float theta[D];
-    float y[D];
+    float y[YD];
     float prior;      // prior_log_prob(theta)         (cache of a pure function of the state)
     float kern;       // calculate_log_kernel(y)       (cache)
     float q;          // global/importance log_prob(theta)  (cache)
@@ -278,11 +321,11 @@ struct Chain {
     uint32_t n_moves;
 };
 
-template <int D>
-GLABC_DEV void refresh_cache(const StepArgs<D>& a, Chain<D>& c)
+template <int D, int YD>
+GLABC_DEV void refresh_cache(const StepArgs<D, YD>& a, Chain<D, YD>& c)
 {
     c.prior = dist_log_prob<D>(a.prior, c.theta);
-    c.kern = model_log_kernel<D>(a, c.y);
+    c.kern = model_log_kernel<D, YD>(a, c.y);
     c.q = dist_log_prob<D>(a.global, c.theta);
 }
 
@@ -299,8 +342,8 @@ GLABC_DEV void refresh_cache(const StepArgs<D>& a, Chain<D>& c)
 //                 double against a double uniform         GLMCMC.py:75-84, 7-22
 //   MH          : log(u) < ((prior'+K') - prior) - K                       GLMCMC.py:96-99
 //                 log(u) < ((((prior'+K') + q) - q') - prior) - K          GlobalMCMC.py:44-47
-template <int ALGO, int D, int N, int L, int VAR>
-GLABC_DEV bool chain_step(const StepArgs<D>& a, const Rng& rng, uint32_t step, int sub, Chain<D>& c)
+template <int ALGO, int D, int YD, int N, int L, int VAR>
+GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t step, int sub, Chain<D, YD>& c)
 {
     constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
     constexpr int NL = (N + L - 1) / L;            // candidate slots per lane
@@ -309,7 +352,8 @@ GLABC_DEV bool chain_step(const StepArgs<D>& a, const Rng& rng, uint32_t step, i
     // (Philox slot 0) is drawn there, in the same instruction stream as the other lanes'
     // candidates of that pass, and that pass runs first so candidate 0 knows its branch.
     constexpr bool FREE_SLOT = (L > 1) && (N % L != 0) && (NL >= 2);
-    constexpr int SPP = (2 * D + 3) / 4;
+    constexpr int M = D + YD;                          // draws per candidate: D proposal + YD simulator
+    constexpr int SPP = (M + 3) / 4;
 
     uint32_t hw[4];
     float log_u = 0.0f;
@@ -339,7 +383,7 @@ GLABC_DEV bool chain_step(const StepArgs<D>& a, const Rng& rng, uint32_t step, i
     }
 
     // ---- this lane's candidates ----
-    float th[NL][D], yy[NL][D], lw[NL], pr[NL], kk[NL], wl[NL];
+    float th[NL][D], yy[NL][YD], lw[NL], pr[NL], kk[NL], wl[NL];
     bool acc_mh = false;
     const bool g_uni = !GU && a.global.kind == GLABC_DIST_UNIFORM;
     const bool l_uni = !GU && a.local.kind == GLABC_DIST_UNIFORM;
@@ -367,14 +411,13 @@ GLABC_DEV bool chain_step(const StepArgs<D>& a, const Rng& rng, uint32_t step, i
         }
         const bool loc = first && !is_global;
         const bool uni = loc ? l_uni : g_uni;
-        float nrm[2 * D], e[D], s[D];
+        float nrm[2 * ((M + 1) / 2)], e[D], s[YD];
 #pragma unroll
-        for (int i = 0; i < D; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
+        for (int i = 0; 2 * i < M; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            e[i] = (!GU && uni) ? glabc_uniform_f32(w[i]) : nrm[i];
-            s[i] = nrm[D + i];
-        }
+        for (int i = 0; i < D; ++i) e[i] = (!GU && uni) ? glabc_uniform_f32(w[i]) : nrm[i];
+#pragma unroll
+        for (int i = 0; i < YD; ++i) s[i] = nrm[D + i];
 #pragma unroll
         for (int q = 0; q < D; ++q) {
             const float p0 = loc ? a.local.p0[q] : a.global.p0[q];
@@ -383,9 +426,9 @@ GLABC_DEV bool chain_step(const StepArgs<D>& a, const Rng& rng, uint32_t step, i
             th[r][q] = loc ? (t + c.theta[q]) : t;                            // GLMCMC.py:91
         }
         const float lq = dist_forward_log_p<D, GU>(a.global, e);              // unused by the local move
-        model_simulate<D>(a, th[r], s, yy[r]);
+        model_simulate<D, YD>(a, th[r], s, yy[r]);
         pr[r] = dist_log_prob<D, GU>(a.prior, th[r]);
-        kk[r] = model_log_kernel<D>(a, yy[r]);
+        kk[r] = model_log_kernel<D, YD>(a, yy[r]);
         const float pk = pr[r] + kk[r];
         lw[r] = pk - lq;                                                      // GLMCMC.py:74
         if (r == 0) {
@@ -435,39 +478,35 @@ GLABC_DEV bool chain_step(const StepArgs<D>& a, const Rng& rng, uint32_t step, i
         const int slot = (ind - 1) / L;
         // this lane's candidate in the winning slot (conditional moves over the unrolled slots keep
         // everything in VGPRs; a run-time array index would be promoted to LDS / scratch)
-        float nt[D], ny[D], nlw = lw[0], npr = pr[0], nkk = kk[0];
+        float nt[D], ny[YD], nlw = lw[0], npr = pr[0], nkk = kk[0];
 #pragma unroll
-        for (int q = 0; q < D; ++q) {
-            nt[q] = th[0][q];
-            ny[q] = yy[0][q];
-        }
+        for (int q = 0; q < D; ++q) nt[q] = th[0][q];
+#pragma unroll
+        for (int q = 0; q < YD; ++q) ny[q] = yy[0][q];
 #pragma unroll
         for (int r = 1; r < NL; ++r) {
             if (slot == r) {
 #pragma unroll
-                for (int q = 0; q < D; ++q) {
-                    nt[q] = th[r][q];
-                    ny[q] = yy[r][q];
-                }
+                for (int q = 0; q < D; ++q) nt[q] = th[r][q];
+#pragma unroll
+                for (int q = 0; q < YD; ++q) ny[q] = yy[r][q];
                 nlw = lw[r];
                 npr = pr[r];
                 nkk = kk[r];
             }
         }
 #pragma unroll
-        for (int q = 0; q < D; ++q) {
-            nt[q] = group_get_dyn<L>(nt[q], owner);
-            ny[q] = group_get_dyn<L>(ny[q], owner);
-        }
+        for (int q = 0; q < D; ++q) nt[q] = group_get_dyn<L>(nt[q], owner);
+#pragma unroll
+        for (int q = 0; q < YD; ++q) ny[q] = group_get_dyn<L>(ny[q], owner);
         nlw = group_get_dyn<L>(nlw, owner);
         npr = group_get_dyn<L>(npr, owner);
         nkk = group_get_dyn<L>(nkk, owner);
         if (moved) {
 #pragma unroll
-            for (int q = 0; q < D; ++q) {
-                c.theta[q] = nt[q];
-                c.y[q] = ny[q];
-            }
+            for (int q = 0; q < D; ++q) c.theta[q] = nt[q];
+#pragma unroll
+            for (int q = 0; q < YD; ++q) c.y[q] = ny[q];
             c.prior = npr;
             c.kern = nkk;
             c.q = dist_log_prob<D, GU>(a.global, c.theta);

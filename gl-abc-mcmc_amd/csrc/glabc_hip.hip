@@ -20,18 +20,17 @@
 
 namespace glabc {
 
-template <int D>
-__global__ void __launch_bounds__(BLOCK) init_weights_kernel(const StepArgs<D> a)
+template <int D, int YD>
+__global__ void __launch_bounds__(BLOCK) init_weights_kernel(const StepArgs<D, YD> a)
 {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.n_chains) return;
-    Chain<D> c;
+    Chain<D, YD> c;
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        c.theta[j] = a.theta[j * a.stride + i];
-        c.y[j] = a.y[j * a.stride + i];
-    }
-    refresh_cache<D>(a, c);
+    for (int j = 0; j < D; ++j) c.theta[j] = a.theta[j * a.stride + i];
+#pragma unroll
+    for (int j = 0; j < YD; ++j) c.y[j] = a.y[j * a.stride + i];
+    refresh_cache<D, YD>(a, c);
     a.log_w[i] = (c.prior + c.kern) - c.q;                         // GLMCMC.py:52-55
     a.flags[i] = a.flags[i] | GLABC_FLAG_LOCAL;                    // GLMCMC.py:50
 }
@@ -389,13 +388,19 @@ static int check_dist(const glabc_dist* g, int dim)
 static int check_model(const glabc_model* m)
 {
     if (!m) return GLABC_ERR_NULL;
-    if (m->sim_kind != GLABC_SIM_ABS_GAUSS) return GLABC_ERR_KIND;
-    if (m->theta_dim < 1 || m->theta_dim > GLABC_MAX_DIM || m->y_dim != m->theta_dim) return GLABC_ERR_DIM;
+    if (m->sim_kind != GLABC_SIM_ABS_GAUSS && m->sim_kind != GLABC_SIM_GK) return GLABC_ERR_KIND;
+    if (m->theta_dim < 1 || m->theta_dim > GLABC_MAX_DIM || m->y_dim < 1 || m->y_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
     int rc = check_dist(&m->prior, m->theta_dim);
     if (rc) return rc;
-    rc = check_dist(&m->noise, m->y_dim);
-    if (rc) return rc;
-    if (m->noise.kind != GLABC_DIST_DIAG_GAUSS) return GLABC_ERR_KIND;
+    if (m->sim_kind == GLABC_SIM_GK) {
+        if (m->theta_dim != 4 || m->y_dim != 8) return GLABC_ERR_DIM;          // the compiled g-and-k shape
+        if (!std::isfinite(m->gk_c)) return GLABC_ERR_ARG;
+    } else {
+        if (m->y_dim != m->theta_dim) return GLABC_ERR_DIM;
+        rc = check_dist(&m->noise, m->y_dim);
+        if (rc) return rc;
+        if (m->noise.kind != GLABC_DIST_DIAG_GAUSS) return GLABC_ERR_KIND;
+    }
     if (!std::isfinite(m->kern_log_scale) || !(m->kern_scale > 0.0f) || !std::isfinite(m->kern_scale) ||
         !std::isfinite(m->kern_c0))
         return GLABC_ERR_ARG;
@@ -421,14 +426,16 @@ static DistArgs<D> pack_dist(const glabc_dist* g)
     return o;
 }
 
-template <int D>
-static StepArgs<D> pack_args(const glabc_model* m, const glabc_dist* local, const glabc_dist* global,
-                             const glabc_chains* c, const glabc_run* r)
+template <int D, int YD = D>
+static StepArgs<D, YD> pack_args(const glabc_model* m, const glabc_dist* local, const glabc_dist* global,
+                                 const glabc_chains* c, const glabc_run* r)
 {
-    StepArgs<D> a;
+    StepArgs<D, YD> a;
     std::memset(&a, 0, sizeof a);
     a.prior = pack_dist<D>(&m->prior);
-    for (int j = 0; j < D; ++j) {
+    a.sim_kind = m->sim_kind;
+    a.gk_c = m->gk_c;
+    for (int j = 0; j < YD; ++j) {
         a.noise_loc[j] = m->noise.p0[j];
         a.noise_scale[j] = m->noise.p2[j];
         a.y_obs[j] = m->y_obs[j];
@@ -526,12 +533,16 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
     if (c->n_chains == 0 || r->n_steps == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;
     const int lanes = algo == ALGO_GLMCMC ? pick_lanes(r->lanes_per_chain, r->batch_size, c->n_chains) : 1;
-    switch (m->theta_dim) {
-    case 1: rc = launch_sampler_dim<1>(algo, r->batch_size, lanes, pack_args<1>(m, local, global, c, r), s); break;
-    case 2: rc = launch_sampler_dim<2>(algo, r->batch_size, lanes, pack_args<2>(m, local, global, c, r), s); break;
-    case 3: rc = launch_sampler_dim<3>(algo, r->batch_size, lanes, pack_args<3>(m, local, global, c, r), s); break;
-    case 4: rc = launch_sampler_dim<4>(algo, r->batch_size, lanes, pack_args<4>(m, local, global, c, r), s); break;
-    default: return GLABC_ERR_DIM;
+    if (m->sim_kind == GLABC_SIM_GK) {
+        rc = launch_sampler_dim<4, 8>(algo, r->batch_size, lanes, pack_args<4, 8>(m, local, global, c, r), s);
+    } else {
+        switch (m->theta_dim) {
+        case 1: rc = launch_sampler_dim<1, 1>(algo, r->batch_size, lanes, pack_args<1>(m, local, global, c, r), s); break;
+        case 2: rc = launch_sampler_dim<2, 2>(algo, r->batch_size, lanes, pack_args<2>(m, local, global, c, r), s); break;
+        case 3: rc = launch_sampler_dim<3, 3>(algo, r->batch_size, lanes, pack_args<3>(m, local, global, c, r), s); break;
+        case 4: rc = launch_sampler_dim<4, 4>(algo, r->batch_size, lanes, pack_args<4>(m, local, global, c, r), s); break;
+        default: return GLABC_ERR_DIM;
+        }
     }
     if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
     return rc;
@@ -573,6 +584,7 @@ __attribute__((visibility("default"))) int glabc_glmala_steps(const glabc_model*
 {
     int rc = check_model(model);
     if (rc) return rc;
+    if (model->sim_kind != GLABC_SIM_ABS_GAUSS) return GLABC_ERR_KIND;
     rc = check_dist(importance, model->theta_dim);
     if (rc) return rc;
     if (!mala || !r) return GLABC_ERR_NULL;
@@ -650,6 +662,7 @@ __attribute__((visibility("default"))) int glabc_pool_weights(const glabc_model*
 {
     int rc = check_model(model);
     if (rc) return rc;
+    if (model->sim_kind != GLABC_SIM_ABS_GAUSS) return GLABC_ERR_KIND;
     if (!theta || !log_q || !x_out || !w_out) return GLABC_ERR_NULL;
     if (n_rows < 0 || row_id0 < 0) return GLABC_ERR_ARG;
     if (n_rows == 0) return GLABC_OK;
@@ -683,6 +696,7 @@ __attribute__((visibility("default"))) int glabc_glmcmc_nf_step(const glabc_mode
     if (rc) return rc;
     rc = check_dist(local, model->theta_dim);
     if (rc) return rc;
+    if (model->sim_kind != GLABC_SIM_ABS_GAUSS) return GLABC_ERR_KIND;
     if (!pool || !c || !r) return GLABC_ERR_NULL;
     if (!pool->theta || !pool->x || !pool->w || !pool->log_q_old || !pool->kk || !c->theta || !c->y) return GLABC_ERR_NULL;
     if (c->n_chains < 0 || c->stride < c->n_chains || c->chain0 < 0 || pool->step_size < 1) return GLABC_ERR_ARG;
@@ -750,11 +764,15 @@ __attribute__((visibility("default"))) int glabc_init_weights(const glabc_model*
     if (c->n_chains == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(grid_for(c->n_chains, BLOCK)), block(BLOCK);
+    if (model->sim_kind == GLABC_SIM_GK) {
+        hipLaunchKernelGGL((init_weights_kernel<4, 8>), grid, block, 0, s, pack_args<4, 8>(model, nullptr, importance, c, nullptr));
+        return finish_launch();
+    }
     switch (model->theta_dim) {
-    case 1: hipLaunchKernelGGL(init_weights_kernel<1>, grid, block, 0, s, pack_args<1>(model, nullptr, importance, c, nullptr)); break;
-    case 2: hipLaunchKernelGGL(init_weights_kernel<2>, grid, block, 0, s, pack_args<2>(model, nullptr, importance, c, nullptr)); break;
-    case 3: hipLaunchKernelGGL(init_weights_kernel<3>, grid, block, 0, s, pack_args<3>(model, nullptr, importance, c, nullptr)); break;
-    case 4: hipLaunchKernelGGL(init_weights_kernel<4>, grid, block, 0, s, pack_args<4>(model, nullptr, importance, c, nullptr)); break;
+    case 1: hipLaunchKernelGGL((init_weights_kernel<1, 1>), grid, block, 0, s, pack_args<1>(model, nullptr, importance, c, nullptr)); break;
+    case 2: hipLaunchKernelGGL((init_weights_kernel<2, 2>), grid, block, 0, s, pack_args<2>(model, nullptr, importance, c, nullptr)); break;
+    case 3: hipLaunchKernelGGL((init_weights_kernel<3, 3>), grid, block, 0, s, pack_args<3>(model, nullptr, importance, c, nullptr)); break;
+    case 4: hipLaunchKernelGGL((init_weights_kernel<4, 4>), grid, block, 0, s, pack_args<4>(model, nullptr, importance, c, nullptr)); break;
     default: return GLABC_ERR_DIM;
     }
     return finish_launch();

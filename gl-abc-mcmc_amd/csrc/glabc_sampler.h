@@ -1,6 +1,6 @@
 // glabc_sampler.h -- the fused sampler kernel and its per-dimension launcher.
 //
-// sampler_kernel<ALGO, D, N, L, VAR>: K iterations of GLMCMC / GlobalMCMC for every chain of
+// sampler_kernel<ALGO, D, YD, N, L, VAR>: K iterations of GLMCMC / GlobalMCMC for every chain of
 // the shard in ONE launch.  Chain state is loaded once, lives in VGPRs for the K
 // iterations, and is stored once; per iteration only the Theta_Re history row (chain-major,
 // coalesced) leaves the CU.  L lanes cooperate on a chain (glabc_device.h).
@@ -15,8 +15,8 @@ namespace glabc {
 
 constexpr int BLOCK = 64;      // one wavefront per workgroup: 65 536 chains x L lanes spread evenly over 1024 SIMDs
 
-template <int ALGO, int D, int N, int L, int VAR>
-__global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D> a)
+template <int ALGO, int D, int YD, int N, int L, int VAR>
+__global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D, YD> a)
 {
     const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const int64_t chain = tid / L;
@@ -26,16 +26,15 @@ __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D> a)
                                                            // group exchanges need every lane of the wave alive
     const bool writer = valid && sub == 0;
 
-    Chain<D> c;
+    Chain<D, YD> c;
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        c.theta[j] = a.theta[j * a.stride + i];
-        c.y[j] = a.y[j * a.stride + i];
-    }
+    for (int j = 0; j < D; ++j) c.theta[j] = a.theta[j * a.stride + i];
+#pragma unroll
+    for (int j = 0; j < YD; ++j) c.y[j] = a.y[j * a.stride + i];
     c.log_w = (ALGO == ALGO_GLMCMC) ? a.log_w[i] : 0.0f;
     c.flags = (ALGO == ALGO_GLMCMC) ? a.flags[i] : 0u;
     c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
-    refresh_cache<D>(a, c);
+    refresh_cache<D, YD>(a, c);
 
     constexpr int TRI = D * (D + 1) / 2;
     const bool mom = a.sum_theta != nullptr;
@@ -65,7 +64,7 @@ __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D> a)
 #pragma unroll
         for (int j = 0; j < D; ++j) prev[j] = c.theta[j];
 
-        const bool moved = chain_step<ALGO, D, N, L, VAR>(a, rng, step, sub, c);
+        const bool moved = chain_step<ALGO, D, YD, N, L, VAR>(a, rng, step, sub, c);
         c.n_moves += moved ? 1u : 0u;
 
         if (hist && writer) {                                       // Theta_Re[i,:] = Theta_old, GLMCMC.py:89,104
@@ -90,10 +89,9 @@ __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D> a)
 
     if (writer) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            a.theta[j * a.stride + i] = c.theta[j];
-            a.y[j * a.stride + i] = c.y[j];
-        }
+        for (int j = 0; j < D; ++j) a.theta[j * a.stride + i] = c.theta[j];
+#pragma unroll
+        for (int j = 0; j < YD; ++j) a.y[j * a.stride + i] = c.y[j];
         if (ALGO == ALGO_GLMCMC) {
             a.log_w[i] = c.log_w;
             a.flags[i] = c.flags;
@@ -113,7 +111,7 @@ __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D> a)
 
 // host-side launcher of one theta_dim; defined in glabc_sampler_dim.hip (one TU per D).
 // lanes = lanes per chain actually compiled for (1, 2 or 4).  Returns a glabc_status.
-template <int D>
-int launch_sampler_dim(int algo, int n_batch, int lanes, const StepArgs<D>& a, hipStream_t stream);
+template <int D, int YD>
+int launch_sampler_dim(int algo, int n_batch, int lanes, const StepArgs<D, YD>& a, hipStream_t stream);
 
 }  // namespace glabc

@@ -17,6 +17,7 @@ DIST_UNIFORM = 1
 DIST_GAMMA = 2
 
 SIM_ABS_GAUSS = 0
+SIM_GK = 1
 
 FLAG_LOCAL = 1
 FLAG_TH64 = 2
@@ -46,7 +47,7 @@ class Model(C.Structure):
         ("sim_kind", C.c_int32),
         ("theta_dim", C.c_int32),
         ("y_dim", C.c_int32),
-        ("reserved", C.c_int32),
+        ("gk_c", C.c_float),
         ("prior", Dist),
         ("noise", Dist),
         ("y_obs", _f8),

@@ -74,14 +74,17 @@ typedef struct glabc_dist {
 
 /* ---- the Model callbacks: glabcmcmc/examples/Mixture.py:5-53 ------------- */
 typedef enum glabc_sim_kind {
-    GLABC_SIM_ABS_GAUSS = 0        /* y = |theta| + noise, noise ~ DiagGaussian   Mixture.py:13-26 */
+    GLABC_SIM_ABS_GAUSS = 0,       /* y = |theta| + noise, noise ~ DiagGaussian   Mixture.py:13-26 */
+    GLABC_SIM_GK = 1               /* g-and-k order statistics (BASELINE config 4; no counterpart in the reference tree --
+                                      the Model is the build's own, glabcmcmc_amd/examples/GK.py): theta = (A, B, g, k),
+                                      y = sort_j( A + B (1 + c tanh(g z_j/2)) (1 + z_j^2)^k z_j ), z_j ~ N(0,1), j < y_dim = 8 */
 } glabc_sim_kind;
 
 typedef struct glabc_model {
     int32_t sim_kind;              /* glabc_sim_kind */
     int32_t theta_dim;             /* Mixture.py:8  */
     int32_t y_dim;                 /* Mixture.py:10 */
-    int32_t reserved;
+    float gk_c;                    /* GLABC_SIM_GK: the constant c (0.8) */
     glabc_dist prior;              /* prior_log_prob      Mixture.py:28-31 */
     glabc_dist noise;              /* generate_samples    Mixture.py:19    */
     float y_obs[GLABC_MAX_DIM];    /* discrepancy = ||y - y_obs||_2         Mixture.py:9,33-36 */

@@ -167,10 +167,35 @@ ORACLE_API int oracle_dist_forward(const glabc_dist* dist, const float* noise, i
 /* ------------------------------------------------------------------------- */
 /* examples/Mixture.py -- the Model callbacks */
 
-/* generate_samples for one theta and one simulation, Mixture.py:19-23:
- *   y = |theta| + (loc + exp(log_scale)*eps) */
+/* tanh through the specified exp (the g-and-k quantile function below) */
+static float gk_tanhf(float x)
+{
+    float e = glabc_expf(-2.0f * fabsf(x));
+    float r = (1.0f - e) / (1.0f + e);
+    return x < 0.0f ? -r : r;
+}
+
+/* generate_samples for one theta and one simulation.
+ *   GLABC_SIM_ABS_GAUSS, Mixture.py:19-23:  y = |theta| + (loc + exp(log_scale)*eps)
+ *   GLABC_SIM_GK (the build's own Model, no counterpart in the reference tree; glabcmcmc_amd/examples/GK.py):
+ *       y_j = A + B (1 + c tanh(g z_j/2)) (1 + z_j^2)^k z_j,  theta = (A, B, g, k), then sorted ascending */
 static void model_simulate(const glabc_model* m, const float* theta, const float* eps, float* y)
 {
+    if (m->sim_kind == GLABC_SIM_GK) {
+        for (int j = 0; j < m->y_dim; ++j) {
+            float z = eps[j];
+            float t = gk_tanhf((theta[2] * z) * 0.5f);
+            float pw = glabc_expf(theta[3] * glabc_logf(1.0f + z * z));
+            y[j] = theta[0] + ((theta[1] * (1.0f + m->gk_c * t)) * pw) * z;
+        }
+        for (int a = 1; a < m->y_dim; ++a) {                    /* insertion sort: any correct sort gives the same array */
+            float v = y[a];
+            int b = a - 1;
+            while (b >= 0 && y[b] > v) { y[b + 1] = y[b]; --b; }
+            y[b + 1] = v;
+        }
+        return;
+    }
     for (int j = 0; j < m->y_dim; ++j) {
         float noise = m->noise.p0[j] + m->noise.p2[j] * eps[j];
         y[j] = fabsf(theta[j]) + noise;
@@ -211,11 +236,13 @@ static float model_log_kernel(const glabc_model* m, const float* y)
 static int model_check(const glabc_model* m)
 {
     if (!m) return GLABC_ERR_NULL;
-    if (m->sim_kind != GLABC_SIM_ABS_GAUSS) return GLABC_ERR_KIND;
+    if (m->sim_kind != GLABC_SIM_ABS_GAUSS && m->sim_kind != GLABC_SIM_GK) return GLABC_ERR_KIND;
     if (m->theta_dim < 1 || m->theta_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
     if (m->y_dim < 1 || m->y_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    if (m->prior.dim != m->theta_dim) return GLABC_ERR_DIM;
+    if (m->sim_kind == GLABC_SIM_GK) return m->theta_dim == 4 ? 0 : GLABC_ERR_DIM;
     if (m->y_dim != m->theta_dim) return GLABC_ERR_DIM;        /* |theta| + noise is elementwise */
-    if (m->prior.dim != m->theta_dim || m->noise.dim != m->y_dim) return GLABC_ERR_DIM;
+    if (m->noise.dim != m->y_dim) return GLABC_ERR_DIM;
     if (m->noise.kind != GLABC_DIST_DIAG_GAUSS) return GLABC_ERR_KIND;
     return 0;
 }

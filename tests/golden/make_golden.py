@@ -47,6 +47,8 @@ import glabcmcmc.GlobalMCMC as rglobal          # noqa: E402
 import glabcmcmc.GLMALA as rglmala              # noqa: E402
 import glabcmcmc.ESJD as resjd                  # noqa: E402
 from Mixture import Mixture_set                 # noqa: E402
+from glabcmcmc_amd.examples.GK import GK_set     # noqa: E402  (the build's own g-and-k Model: BASELINE config 4 has
+                                                 #  no model in the reference tree; it is DRIVEN by the reference's loops)
 
 import oracle_lib                               # noqa: E402
 
@@ -212,8 +214,12 @@ def reference_constants(cfg):
     return out
 
 
+def make_model(cfg):
+    return GK_set(cfg["epsilon"]) if cfg.get("model") == "gk" else Mixture_set(cfg["epsilon"])
+
+
 def run_reference(algo, cfg, theta0, y0, tape):
-    model = Mixture_set(cfg["epsilon"])
+    model = make_model(cfg)
     local = make_dist(cfg["local"])
     glob = make_dist(cfg["global"])
     T = cfg["T"]
@@ -232,12 +238,23 @@ def run_reference(algo, cfg, theta0, y0, tape):
 
 def sampler_fixture(name, algo, cfg, mode):
     L = oracle_lib.load()
-    d = yd = 2
+    gk = cfg.get("model") == "gk"
+    d, yd = (4, 8) if gk else (2, 2)
     C, T, N = cfg["C"], cfg["T"], cfg["N"]
     P = N if algo in ("glmcmc", "glmala") else 1
     rng = np.random.default_rng(cfg["seed"] + 1000)
-    theta0 = (rng.standard_normal((C, d)) * cfg.get("theta0_sd", 0.0)).astype(np.float32)
-    y0 = (np.abs(theta0) + np.sqrt(np.float32(0.05)) * rng.standard_normal((C, yd)).astype(np.float32)).astype(np.float32)
+    if gk:
+        theta0 = rng.uniform(0.5, 5.0, (C, d)).astype(np.float32)
+        zz = torch.from_numpy(rng.standard_normal((C, yd)).astype(np.float32))
+        saved = torch.randn
+        torch.randn = lambda *a, **k: zz
+        try:
+            y0 = GK_set(cfg["epsilon"]).generate_samples(torch.from_numpy(theta0)).numpy().copy()
+        finally:
+            torch.randn = saved
+    else:
+        theta0 = (rng.standard_normal((C, d)) * cfg.get("theta0_sd", 0.0)).astype(np.float32)
+        y0 = (np.abs(theta0) + np.sqrt(np.float32(0.05)) * rng.standard_normal((C, yd)).astype(np.float32)).astype(np.float32)
     ug = cfg["global"][0] == "uniform"
     ul = cfg["local"][0] == "uniform"
     chains = np.zeros((T + 1, C, d), np.float32)
@@ -318,6 +335,16 @@ SAMPLER_FIXTURES = {
                                                   **{"global": ("uniform", [-3.0, -3.0], [3.0, 3.0])}), "philox"),
     "glmala_philox_uniform": ("glmala", dict(epsilon=0.3, gf=0.5, N=4, tau=0.3, num_grad=12, C=8, T=300, seed=35,
                                              theta0_sd=1.0, local=G2(0.35), **{"global": ("uniform", [-3.0, -3.0], [3.0, 3.0])}), "philox"),
+    # BASELINE config 4's model (g-and-k, theta_dim 4, the build's own Model class) driven by the reference's loops
+    "glmcmc_philox_gk": ("glmcmc", dict(model="gk", epsilon=1.0, gf=0.8, N=5, C=16, T=600, seed=51,
+                                        local=("gauss", [0.0] * 4, [0.15] * 4),
+                                        **{"global": ("uniform", [0.0] * 4, [10.0] * 4)}), "philox"),
+    "glmcmc_philox_gk_gauss": ("glmcmc", dict(model="gk", epsilon=0.7, gf=0.5, N=3, C=12, T=500, seed=52,
+                                              local=("gauss", [0.0] * 4, [0.2, 0.1, 0.2, 0.1]),
+                                              **{"global": ("gauss", [3.0, 1.5, 2.0, 1.0], [2.0, 1.0, 1.5, 0.7])}), "philox"),
+    "globalmcmc_philox_gk": ("globalmcmc", dict(model="gk", epsilon=1.0, gf=0.5, N=1, C=12, T=800, seed=53,
+                                                local=("gauss", [0.0] * 4, [0.15] * 4),
+                                                **{"global": ("uniform", [0.0] * 4, [10.0] * 4)}), "philox"),
     # stored-tape fixtures (NumPy numbers; independent of the Philox specification)
     "glmcmc_tape_small": ("glmcmc", dict(epsilon=0.2, gf=0.8, N=5, C=8, T=300, seed=21, theta0_sd=1.0,
                                          local=G2(0.35), **{"global": G2(1.0)}), "tape"),

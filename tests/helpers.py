@@ -35,10 +35,15 @@ def descriptors(cfg, consts=None):
     host-computed float32 constants (exp(log_scale), log(eps) ...) are then taken from the fixture, i.e.
     the values the reference computed on the machine that generated the golden chains -- torch's CPU
     log / exp differ in the last bits between CPU types, and GLMALA's chains depend on them."""
-    model = Mixture_set(cfg["epsilon"]).descriptor()
+    gk = cfg.get("model") == "gk"
+    if gk:
+        from glabcmcmc_amd.examples.GK import GK_set
+        model = GK_set(cfg["epsilon"]).descriptor()
+    else:
+        model = Mixture_set(cfg["epsilon"]).descriptor()
     local, glob = make_dist(cfg["local"]).descriptor(), make_dist(cfg["global"]).descriptor()
     if consts is not None:
-        for j in range(2):
+        for j in range(0 if gk else 2):
             model.noise.p1[j] = float(consts["c_noise_log_scale"][j])
             model.noise.p2[j] = float(consts["c_noise_scale"][j])
         model.kern_log_scale = float(consts["c_kern_log_scale"][0])
@@ -55,6 +60,7 @@ SAMPLER_GOLDENS = [
     "glmcmc_philox_bench", "glmcmc_philox_n8", "glmcmc_philox_n1", "glmcmc_philox_n3", "glmcmc_philox_n16",
     "glmcmc_philox_uniform", "globalmcmc_philox_bench", "globalmcmc_philox_wide",
     "glmcmc_tape_small", "globalmcmc_tape_small",
+    "glmcmc_philox_gk", "glmcmc_philox_gk_gauss", "globalmcmc_philox_gk",
 ]
 
 # reference run with a correctly rounded torch.sqrt (see make_golden.py): bit parity expected

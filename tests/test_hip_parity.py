@@ -113,6 +113,68 @@ def test_hip_equals_oracle(hip, oracle, case):
     assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
 
 
+GK_CASES = [
+    ("glmcmc", 5, 0.8, 1.0, ("gauss", [0.0] * 4, [0.15] * 4), ("uniform", [0.0] * 4, [10.0] * 4), 1500, 200, 1),
+    ("glmcmc", 5, 0.8, 1.0, ("gauss", [0.0] * 4, [0.15] * 4), ("uniform", [0.0] * 4, [10.0] * 4), 700, 150, 2),
+    ("glmcmc", 3, 0.5, 0.7, ("gauss", [0.0] * 4, [0.2, 0.1, 0.2, 0.1]), ("gauss", [3.0, 1.5, 2.0, 1.0], [2.0, 1.0, 1.5, 0.7]), 700, 150, 4),
+    ("glmcmc", 8, 0.9, 0.5, ("uniform", [-0.3] * 4, [0.3] * 4), ("uniform", [0.0] * 4, [10.0] * 4), 300, 100, 1),
+    ("globalmcmc", 1, 0.5, 1.0, ("gauss", [0.0] * 4, [0.15] * 4), ("uniform", [0.0] * 4, [10.0] * 4), 1500, 300, 0),
+]
+
+
+@pytest.mark.parametrize("case", GK_CASES, ids=lambda c: "%s-N%d-%s-%s-L%d" % (c[0], c[1], c[4][0], c[5][0], c[8]))
+def test_gk_model_equals_oracle(hip, oracle, case):
+    """BASELINE config 4's model (g-and-k order statistics, theta_dim 4, y_dim 8): kernel == oracle, bit for bit."""
+    algo, N, gf, eps, lspec, gspec, n, T, lanes = case
+    cfg = dict(model="gk", epsilon=eps, local=lspec, **{"global": gspec})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(n + T + N)
+    theta0 = rng.uniform(0.5, 5.0, (n, 4)).astype(np.float32)
+    y0 = np.sort(rng.uniform(1.0, 8.0, (n, 8)).astype(np.float32), axis=1)
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    hist, chains, mom = hip_run(algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True, lanes=lanes)
+    hh, hc, hm = oracle_run(oracle, algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True)
+    same = bits(hist) == bits(hh)
+    assert same.all(), "first mismatch at (t, dim, chain) = %s" % (np.argwhere(~same)[0],)
+    assert_same_state(chains, hc, algo == "glmcmc")
+    assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
+    assert hc.n_moves.sum() > 0
+
+
+def test_gk_model_callbacks_on_gpu(hip, oracle):
+    from glabcmcmc_amd.examples.GK import GK_set
+    m = GK_set(0.8)
+    desc = m.descriptor()
+    rng = np.random.default_rng(3)
+    theta = rng.uniform(-1, 11, (500, 4)).astype(np.float32)
+    y = np.sort(rng.uniform(0, 9, (500, 8)).astype(np.float32), axis=1)
+    o = np.empty(500, np.float32)
+    assert oracle.oracle_model_prior_log_prob(C.byref(desc), theta.ctypes.data, 500, o.ctypes.data) == 0
+    assert np.array_equal(bits(m.prior_log_prob(torch.from_numpy(theta).cuda()).cpu().numpy()), bits(o))
+    assert np.isinf(o).any() and np.isfinite(o).any()
+    assert oracle.oracle_model_log_kernel(C.byref(desc), y.ctypes.data, 500, o.ctypes.data) == 0
+    assert np.array_equal(bits(m.calculate_log_kernel(torch.from_numpy(y).cuda()).cpu().numpy()), bits(o))
+    assert oracle.oracle_model_discrepancy(C.byref(desc), y.ctypes.data, 500, o.ctypes.data) == 0
+    assert np.array_equal(bits(m.discrepancy(torch.from_numpy(y).cuda()).cpu().numpy()), bits(o))
+
+
+def test_gk_posterior_concentrates(hip):
+    """GLMCMC on the g-and-k model through the public API: chains started from the prior move toward the
+    parameters that generated y_obs (A = 3, B = 1)."""
+    import glabcmcmc_amd as g
+    from glabcmcmc_amd.examples.GK import GK_set
+    m = GK_set(0.6)
+    torch.manual_seed(0)
+    n = 4096
+    theta0 = torch.rand(n, 4) * 10
+    y0 = m.generate_samples(theta0)
+    lp = g.DiagGaussian(4, torch.zeros(1, 4), torch.log(torch.tensor([0.15, 0.1, 0.2, 0.1])))
+    ip = g.Uniform(4, torch.zeros(4), torch.full((4,), 10.0))
+    out = g.GLMCMC(m, 3000, theta0, y0, lp, None, 0.7, ip, 8, seed=5, return_device=True)
+    late = out[2000:].mean(dim=(0, 1)).cpu().numpy()
+    assert abs(late[0] - 3.0) < 0.35 and abs(late[1] - 1.0) < 0.6, late
+
+
 @pytest.mark.parametrize("lanes", [1, 2, 4])
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 6, 8, 13, 16])
 def test_lanes_per_chain_is_only_geometry(hip, oracle, N, lanes):

@@ -130,7 +130,7 @@ def run_oracle(oracle, g, philox_chain0=None):
     """Run the oracle on a sampler golden's configuration; returns the (T+1, C, d) chains."""
     cfg = g["cfg"]
     model, local, glob = descriptors(cfg, g)
-    C_, T, d = g["theta0"].shape[0], cfg["T"], 2
+    C_, T, d = g["theta0"].shape[0], cfg["T"], g["theta0"].shape[1]
     ch = oracle_lib.HostChains(g["theta0"], g["y0"], chain0=cfg.get("chain0", 0))
     hist = np.zeros((T, d, C_), np.float32)
     tape = None
