@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--no-history", action="store_true", help="diagnostic: do not write Theta_Re rows")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default; geometry only)")
     ap.add_argument("--couplings", type=int, default=8, help="nf workload: number of couplings")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the multi-rank control flow on ONE GPU: every rank uses cuda:0 and the collectives "
+                         "run on gloo with CPU copies (numbers are meaningless; RCCL needs one GPU per rank)")
     ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
@@ -158,11 +161,17 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if args.rehearse_gloo else dev           # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from glabcmcmc_amd import engine
     from glabcmcmc_amd.parallel import gather_chain_stats
@@ -220,11 +229,11 @@ def main():
         a.record()              # torch's current stream = the stream run_steps launches on
         one_step()
         b.record()
-    stats = gather_chain_stats(mom, world)          # RCCL all-gather of the per-chain sums (no-op at N=1)
+    stats = gather_chain_stats(mom, world, via=cdev)   # RCCL all-gather of the per-chain sums (no-op at N=1)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

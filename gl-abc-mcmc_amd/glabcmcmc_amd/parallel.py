@@ -34,14 +34,19 @@ def gather_rows(local_rows, world):
     return out.view(world, k, n).permute(1, 0, 2).reshape(k, world * n).contiguous()
 
 
-def gather_moments(mom, world):
-    """engine.Moments of ALL chains of the job (every rank gets the same object)."""
+def gather_moments(mom, world, via=None):
+    """engine.Moments of ALL chains of the job (every rank gets the same object).  `via`: device the
+    collective payload is staged on (default: where the sums live; "cpu" for a gloo rehearsal)."""
     if world == 1:
         return mom
     d = mom.d
     tri = d * (d + 1) // 2
     packed = torch.cat([mom.sum_theta, mom.sum_outer, mom.sum_jump], dim=0)        # [d + 2 tri][n]
-    allrows = gather_rows(packed, world)
+    home = packed.device
+    if via is not None and torch.device(via) != home:
+        allrows = gather_rows(packed.to(via), world).to(home)
+    else:
+        allrows = gather_rows(packed, world)
     out = engine.Moments.__new__(engine.Moments)
     out.n, out.d, out.steps = mom.n * world, d, mom.steps
     out.sum_theta = allrows[:d].contiguous()
@@ -50,10 +55,10 @@ def gather_moments(mom, world):
     return out
 
 
-def gather_chain_stats(mom, world):
+def gather_chain_stats(mom, world, via=None):
     """Per-chain ESJD (ESJD.py:21-24, via glabc_moments_esjd) and pooled posterior moments
     of the whole job from the all-gathered streaming sums."""
-    allm = gather_moments(mom, world)
+    allm = gather_moments(mom, world, via)
     steps = float(allm.steps)
     return {
         "esjd": allm.esjd(),
