@@ -7,7 +7,8 @@
 //
 // The MALA drift is the reference's common-random-number central-difference gradient of a
 // synthetic-likelihood log-ABC: 2 * theta_dim * num_grad simulator calls per local move
-// (numberical_gradient_logABC, GLMALA.py:46-95), looped in-lane here.  Its noise comes from Philox
+// (numberical_gradient_logABC, GLMALA.py:46-95), shared by the lanes of the wavefront (coop_gradient:
+// exact fixed-point sums, so the split over lanes cannot change a bit).  Its noise comes from Philox
 // slots GRAD_BASE + g*GRAD_STRIDE + block (normal n = (k*num + s)*y_dim + j in block n/4), shared by
 // the +d and -d simulations of a coordinate as the reference's reseeding does (GLMALA.py:76,80).
 //
@@ -151,88 +152,142 @@ GLABC_DEV double state_kernel(const StepArgs<D>& a, const MalaChain<D>& c)
     return (double)model_log_kernel<D>(a, y);
 }
 
-// numberical_gradient_logABC, GLMALA.py:46-95, for one float32 theta
+// 64-bit / double lane exchange helpers (two 32-bit moves)
+GLABC_DEV uint64_t shfl_xor_u64(uint64_t v, int m)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+GLABC_DEV double shfl_f64(double v, int src)
+{
+    const uint64_t u = glabc_d2u(v);
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)u, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(u >> 32), src, 64);
+    return glabc_u2d(((uint64_t)hi << 32) | lo);
+}
+
+// numberical_gradient_logABC, GLMALA.py:46-95, wave-cooperative.
+//
+// Every lane of the wavefront calls this; `need` marks the lanes (chains) that want the gradient of their `theta`
+// (float32, GLMALA.py:62).  The n needing chains are dealt to lane groups of G = 64 / 2^ceil(log2 n) lanes; the
+// lanes of a group split the chain's num_grad simulations per coordinate (s = sub, sub + G, ...), accumulate the
+// shifted discrepancies in exact fixed point (glabc_fxsum: integer sums, so the split cannot change a bit), merge
+// the partial sums with xor-shuffles and all finish the statistics; the result goes back to the owning lane.
+// srcmap: 64 ints of LDS (one wavefront per workgroup).
 template <int D>
-GLABC_DEV void numerical_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step, int g, const float (&theta)[D],
-                                  double (&grad)[D])
+GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step, int g, bool need, const float (&theta)[D],
+                             double (&grad)[D], int* srcmap)
 {
     const StepArgs<D>& a = m.s;
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return;                                           // wave-uniform
+    const int lane = (int)(threadIdx.x & 63u);
+    const int n = __popcll(mask);
+    int G = 64;
+    while (G * n > 64) G >>= 1;                                         // wave-uniform
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();                                                    // previous readers of srcmap are done
+    if (need) srcmap[rank] = lane;
+    __syncthreads();
+    const int grp = lane / G, sub = lane - grp * G;
+    const int src = srcmap[grp < n ? grp : 0];                          // idle groups shadow chain 0 (results unused)
+    float th[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) th[j] = __shfl(theta[j], src, 64);
+    Rng r2;
+    r2.c0 = (uint32_t)__shfl((int)rng.c0, src, 64);
+    r2.c1 = (uint32_t)__shfl((int)rng.c1, src, 64);
+    r2.k0 = rng.k0;
+    r2.k1 = rng.k1;
     const int num = m.num_grad;
+    const int rounds = (num + G - 1) / G;
     const float h = 0.1f, hp = 0.00001f;
+    double gout[D];
 #pragma unroll 1
     for (int k = 0; k < D; ++k) {
-        float tp[D], tm[D];
+        float tp[D], tm[D], zero[D], y0p[D], y0m[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            tp[j] = theta[j] + (j == k ? h : 0.0f);                  // GLMALA.py:67
-            tm[j] = theta[j] - (j == k ? h : 0.0f);                  // GLMALA.py:68
+            tp[j] = th[j] + (j == k ? h : 0.0f);                        // GLMALA.py:67
+            tm[j] = th[j] - (j == k ? h : 0.0f);                        // GLMALA.py:68
+            zero[j] = 0.0f;
         }
-        double c_p = 0.0, c_m = 0.0, s1p = 0.0, s2p = 0.0, s1m = 0.0, s2m = 0.0;
-        uint32_t cached_block = 0xffffffffu;
-        glabc_u32x4 blk;
-        blk.v[0] = blk.v[1] = blk.v[2] = blk.v[3] = 0u;
+        model_simulate<D>(a, tp, zero, y0p);                            // centres: the noise-free discrepancies
+        model_simulate<D>(a, tm, zero, y0m);
+        const double c_p = (double)model_discrepancy<D>(a, y0p), c_m = (double)model_discrepancy<D>(a, y0m);
+        glabc_fxsum ap, am;
+        ap.s1 = am.s1 = 0;
+        ap.s2_lo = ap.s2_hi = am.s2_lo = am.s2_hi = 0;
 #pragma unroll 1
-        for (int s = 0; s < num; ++s) {
-            float eps[D], yp[D], ym[D];
+        for (int rd = 0; rd < rounds; ++rd) {
+            const int s = rd * G + sub;
+            if (s < num) {
+                float eps[D], yp[D], ym[D];
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const int64_t n = ((int64_t)k * num + s) * D + j;
-                const uint32_t block = (uint32_t)(n >> 2);
-                if (block != cached_block) {                          // wave-uniform: every lane walks the same (k, s)
-                    blk = glabc_philox4x32_10(rng.c0, rng.c1, step, GRAD_BASE + (uint32_t)g * GRAD_STRIDE + block, rng.k0,
-                                              rng.k1);
-                    cached_block = block;
+                for (int j = 0; j < D; ++j) {
+                    const int64_t nn = ((int64_t)k * num + s) * D + j;
+                    glabc_u32x4 blk = glabc_philox4x32_10(r2.c0, r2.c1, step, GRAD_BASE + (uint32_t)g * GRAD_STRIDE + (uint32_t)(nn >> 2),
+                                                          r2.k0, r2.k1);
+                    const int p = (int)((nn & 3) >> 1);
+                    float z0, z1;
+                    glabc_normal_pair(p ? blk.v[2] : blk.v[0], p ? blk.v[3] : blk.v[1], &z0, &z1);
+                    eps[j] = (nn & 1) ? z1 : z0;
                 }
-                const int p = (int)((n & 3) >> 1);
-                float z0, z1;
-                glabc_normal_pair(p ? blk.v[2] : blk.v[0], p ? blk.v[3] : blk.v[1], &z0, &z1);
-                eps[j] = (n & 1) ? z1 : z0;
+                model_simulate<D>(a, tp, eps, yp);                      // GLMALA.py:78
+                model_simulate<D>(a, tm, eps, ym);                      // GLMALA.py:82 (same noise)
+                glabc_fx_add(&ap, glabc_fx_quantize((double)model_discrepancy<D>(a, yp) - c_p));
+                glabc_fx_add(&am, glabc_fx_quantize((double)model_discrepancy<D>(a, ym) - c_m));
             }
-            model_simulate<D>(a, tp, eps, yp);                        // GLMALA.py:78
-            model_simulate<D>(a, tm, eps, ym);                        // GLMALA.py:82 (same noise)
-            const double dp = (double)model_discrepancy<D>(a, yp), dm = (double)model_discrepancy<D>(a, ym);
-            if (s == 0) {
-                c_p = dp;
-                c_m = dm;
-            }
-            const double ep = dp - c_p, em = dm - c_m;
-            s1p += ep;
-            s2p += ep * ep;
-            s1m += em;
-            s2m += em * em;
         }
-        const double n = (double)num;
-        const double mu_p = c_p + s1p / n, mu_m = c_m + s1m / n;                            // GLMALA.py:86-87
-        const double var_p = (s2p - (s1p * s1p) / n) / (n - 1.0), var_m = (s2m - (s1m * s1m) / n) / (n - 1.0);   // :88-89
+        for (int mm = G >> 1; mm >= 1; mm >>= 1) {                      // merge the group's partial sums (exact integers)
+            glabc_fxsum bp, bm;
+            bp.s1 = (int64_t)shfl_xor_u64((uint64_t)ap.s1, mm);
+            bp.s2_lo = shfl_xor_u64(ap.s2_lo, mm);
+            bp.s2_hi = shfl_xor_u64(ap.s2_hi, mm);
+            bm.s1 = (int64_t)shfl_xor_u64((uint64_t)am.s1, mm);
+            bm.s2_lo = shfl_xor_u64(am.s2_lo, mm);
+            bm.s2_hi = shfl_xor_u64(am.s2_hi, mm);
+            glabc_fx_merge(&ap, &bp);
+            glabc_fx_merge(&am, &bm);
+        }
+        const double nd = (double)num;
+        const double s1p = glabc_fx_sum1(&ap), s2p = glabc_fx_sum2(&ap), s1m = glabc_fx_sum1(&am), s2m = glabc_fx_sum2(&am);
+        const double mu_p = c_p + s1p / nd, mu_m = c_m + s1m / nd;                           // GLMALA.py:86-87
+        const double var_p = (s2p - (s1p * s1p) / nd) / (nd - 1.0), var_m = (s2m - (s1m * s1m) / nd) / (nd - 1.0);   // :88-89
         const double lp = (-0.5 * glabc_log(var_p + m.eps_sq)) - ((0.5 * (mu_p * mu_p)) / (var_p + m.eps_sq));   // :90-91
         const double lm = (-0.5 * glabc_log(var_m + m.eps_sq)) - ((0.5 * (mu_m * mu_m)) / (var_m + m.eps_sq));   // :92-93
         const double gll = (lp - lm) / 0.2;                                                  // :94
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            tp[j] = theta[j] + (j == k ? hp : 0.0f);                                         // :84
-            tm[j] = theta[j] - (j == k ? hp : 0.0f);
+            tp[j] = th[j] + (j == k ? hp : 0.0f);                                            // :84
+            tm[j] = th[j] - (j == k ? hp : 0.0f);
         }
         const float gp = (dist_log_prob<D>(a.prior, tp) - dist_log_prob<D>(a.prior, tm)) / 0.00002f;   // :84-85
         const double gk = gll + (double)gp;                                                  // :95
 #pragma unroll
         for (int j = 0; j < D; ++j)
-            if (j == k) grad[j] = gk;
+            if (j == k) gout[j] = gk;
+    }
+    // back to the owner: chain of rank r was computed by group r, whose first lane is r*G
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const double v = shfl_f64(gout[j], rank * G);
+        if (need) grad[j] = v;
     }
 }
 
-// the MALA local move, GLMALA.py:182-200
+// the MALA local move, GLMALA.py:182-200.  Every lane calls it (the gradients are wave-cooperative);
+// `is_local` marks the chains that take the move this iteration.
 template <int D>
-GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, float u_accept, const float (&zn)[2 * D],
-                         MalaChain<D>& c)
+GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, bool is_local, float u_accept,
+                         const float (&zn)[2 * D], MalaChain<D>& c, int* srcmap)
 {
     const StepArgs<D>& a = m.s;
     float thf[D];
-    if (!(c.flags & GLABC_FLAG_HAS_GRAD)) {                                                  // :183-184
 #pragma unroll
-        for (int j = 0; j < D; ++j) thf[j] = (float)c.theta[j];
-        numerical_gradient<D>(m, rng, step, 0, thf, c.grad);
-        c.flags |= GLABC_FLAG_HAS_GRAD;
-    }
+    for (int j = 0; j < D; ++j) thf[j] = (float)c.theta[j];
+    const bool init = is_local && !(c.flags & GLABC_FLAG_HAS_GRAD);                          // :183-184
+    coop_gradient<D>(m, rng, step, 0, init, thf, c.grad, srcmap);
+    if (init) c.flags |= GLABC_FLAG_HAS_GRAD;
     // Local_proposal_forward, :25-44
     float t[D];
     double x[D];
@@ -249,8 +304,12 @@ GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, fl
     }
     double gprop[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) thf[j] = (float)x[j];                                        // :62
-    numerical_gradient<D>(m, rng, step, 1, thf, gprop);                                      // :187
+    for (int j = 0; j < D; ++j) {
+        thf[j] = (float)x[j];                                                                // :62
+        gprop[j] = 0.0;
+    }
+    coop_gradient<D>(m, rng, step, 1, is_local, thf, gprop, srcmap);                         // :187
+    if (!is_local) return false;
     double y[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -385,9 +444,11 @@ template <int D, int N>
 __global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
 {
     const StepArgs<D>& a = m.s;
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.n_chains) return;
-
+    __shared__ int srcmap[64];
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool valid = tid < a.n_chains;
+    const int64_t i = valid ? tid : a.n_chains - 1;          // tail lanes shadow the last chain (no stores): the cooperative
+                                                             // gradient needs every lane of the wavefront alive
     MalaChain<D> c;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -428,10 +489,10 @@ __global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
 
         glabc_u32x4 h = glabc_philox4x32_10(rng.c0, rng.c1, step, 0u, rng.k0, rng.k1);
         const float u_branch = glabc_uniform_f32(h.v[0]);
-        bool moved;
-        if (u_branch < a.gf) {                                                               // GLMALA.py:151
-            moved = mala_isir_move<D, N>(m, rng, step, glabc_uniform_f64(h.v[2], h.v[3]), c);
-        } else {
+        const bool is_global = u_branch < a.gf;                                              // GLMALA.py:151
+        bool moved = false;
+        if (is_global) moved = mala_isir_move<D, N>(m, rng, step, glabc_uniform_f64(h.v[2], h.v[3]), c);
+        {
             float e[D], s[D], zn[2 * D];
             candidate_draws<D>(rng, step, 0, false, e, s);
 #pragma unroll
@@ -439,13 +500,14 @@ __global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
                 zn[j] = e[j];
                 zn[D + j] = s[j];
             }
-            moved = mala_move<D>(m, rng, step, glabc_uniform_f32(h.v[1]), zn, c);
+            const bool mv = mala_move<D>(m, rng, step, !is_global && valid, glabc_uniform_f32(h.v[1]), zn, c, srcmap);
+            moved = is_global ? moved : mv;
         }
         c.n_moves += moved ? 1u : 0u;
 #pragma unroll
         for (int j = 0; j < D; ++j) cur[j] = (float)c.theta[j];                              // Theta_Re is float32, :148,180,200
 
-        if (hist) {
+        if (hist && valid) {
 #pragma unroll
             for (int j = 0; j < D; ++j) hist[((int64_t)t * D + j) * a.hist_stride] = cur[j];
         }
@@ -465,6 +527,7 @@ __global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
         }
     }
 
+    if (!valid) return;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         m.theta64[j * a.stride + i] = c.theta[j];

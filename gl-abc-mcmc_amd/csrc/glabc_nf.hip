@@ -115,8 +115,69 @@ __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, f
     log_s = (lo1 + hi1) + lds[NF_B3_OFF + 1];
 }
 
+// Two row tiles at once: every W2^T operand fetched from LDS feeds two MFMAs (rows of tile a and of tile b), which
+// halves the LDS reads and address arithmetic per MFMA.  Same arithmetic per row as coupling_params.
+__device__ __forceinline__ void coupling_params2(const float* __restrict__ lds, float z0a, float z0b, int lane, float& shift_a,
+                                                 float& log_s_a, float& shift_b, float& log_s_b)
+{
+    const int half = lane >> 5, col = lane & 31;
+    f32x16 a0, a1, a2, a3, b0, b1, b2, b3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        a0[r] = b0[r] = lds[NF_V4_OFF + 4 * i];
+        a1[r] = b1[r] = lds[NF_V4_OFF + 4 * (i + 32)];
+        a2[r] = b2[r] = lds[NF_V4_OFF + 4 * (i + 64)];
+        a3[r] = b3[r] = lds[NF_V4_OFF + 4 * (i + 96)];
+    }
+    const float* w1 = lds + NF_W1_OFF + half;
+    const float* bb1 = lds + NF_B1_OFF + half;
+    const float* wt = lds + NF_W2_OFF + half * NF_H + col;
+#pragma unroll 4
+    for (int s = 0; s < 64; ++s) {
+        const float w = w1[2 * s], bia = bb1[2 * s];
+        const float ha = __builtin_fmaxf(__builtin_fmaf(w, z0a, bia), 0.0f);
+        const float hb = __builtin_fmaxf(__builtin_fmaf(w, z0b, bia), 0.0f);
+        const float* row = wt + 2 * s * NF_H;
+        const float w0 = row[0], w1v = row[32], w2v = row[64], w3v = row[96];
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, ha, a0, 0, 0, 0);
+        b0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, hb, b0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1v, ha, a1, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1v, hb, b1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2v, ha, a2, 0, 0, 0);
+        b2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2v, hb, b2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3v, ha, a3, 0, 0, 0);
+        b3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3v, hb, b3, 0, 0, 0);
+    }
+    float pa0 = 0.0f, pa1 = 0.0f, pb0 = 0.0f, pb1 = 0.0f;
+    auto epilogue = [&](const f32x16& xa, const f32x16& xb, int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float2 v = *reinterpret_cast<const float2*>(lds + NF_V4_OFF + 4 * i + 1);
+            const float ha = __builtin_fmaxf(xa[r], 0.0f), hb = __builtin_fmaxf(xb[r], 0.0f);
+            pa0 = __builtin_fmaf(v.x, ha, pa0);
+            pa1 = __builtin_fmaf(v.y, ha, pa1);
+            pb0 = __builtin_fmaf(v.x, hb, pb0);
+            pb1 = __builtin_fmaf(v.y, hb, pb1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    epilogue(a0, b0, 0);
+    epilogue(a1, b1, 1);
+    epilogue(a2, b2, 2);
+    epilogue(a3, b3, 3);
+    const float qa0 = __shfl_xor(pa0, 32, 64), qa1 = __shfl_xor(pa1, 32, 64);
+    const float qb0 = __shfl_xor(pb0, 32, 64), qb1 = __shfl_xor(pb1, 32, 64);
+    const float b30 = lds[NF_B3_OFF + 0], b31 = lds[NF_B3_OFF + 1];
+    shift_a = ((half ? qa0 : pa0) + (half ? pa0 : qa0)) + b30;
+    log_s_a = ((half ? qa1 : pa1) + (half ? pa1 : qa1)) + b31;
+    shift_b = ((half ? qb0 : pb0) + (half ? pb0 : qb0)) + b30;
+    log_s_b = ((half ? qb1 : pb1) + (half ? pb1 : qb1)) + b31;
+}
+
 template <bool INVERSE, int NF_TILES_PER_WAVE>
-__global__ void __launch_bounds__(64 * NF_WAVES, 2) nf_kernel(const NfArgs a)
+__global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
 {
     constexpr int NF_ROWS_PER_WG = 32 * NF_WAVES * NF_TILES_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -162,23 +223,34 @@ __global__ void __launch_bounds__(64 * NF_WAVES, 2) nf_kernel(const NfArgs a)
             for (int i = threadIdx.x; i < NF_BLOCK_FLOATS / 4; i += 64 * NF_WAVES) dst[i] = src[i];
         }
         __syncthreads();
-#pragma unroll 1
-        for (int q = 0; q < NF_TILES_PER_WAVE; ++q) {
-            float shift, log_s;
+        auto apply = [&](int q, float shift, float log_s, float t0, float t1) {
             if (INVERSE) {
-                // flows reversed: Permute^-1 (the swap again) then the coupling's inverse
-                const float t0 = z1[q], t1 = z0[q];
-                coupling_params(lds, t0, lane, shift, log_s);
                 z0[q] = t0;
                 z1[q] = (t1 - shift) * glabc_expf(-log_s);
                 lq[q] = lq[q] + (-log_s);
             } else {
-                coupling_params(lds, z0[q], lane, shift, log_s);
                 const float nz = z1[q] * glabc_expf(log_s) + shift;
                 lq[q] = lq[q] - log_s;                                 // log_q -= log_det
                 z1[q] = z0[q];                                         // Permute(2, 'swap')
                 z0[q] = nz;
             }
+        };
+        // inverse: flows reversed -> Permute^-1 (the swap again) first, so the conditioner input is z1
+#pragma unroll
+        for (int q = 0; q + 1 < NF_TILES_PER_WAVE; q += 2) {
+            const float ca = INVERSE ? z1[q] : z0[q], cb = INVERSE ? z1[q + 1] : z0[q + 1];
+            const float ta = z0[q], tb = z0[q + 1];
+            float sa, la, sb, lb;
+            coupling_params2(lds, ca, cb, lane, sa, la, sb, lb);
+            apply(q, sa, la, ca, ta);
+            apply(q + 1, sb, lb, cb, tb);
+        }
+        if constexpr (NF_TILES_PER_WAVE % 2 == 1) {
+            constexpr int q = NF_TILES_PER_WAVE - 1;
+            const float ca = INVERSE ? z1[q] : z0[q], ta = z0[q];
+            float sa, la;
+            coupling_params(lds, ca, lane, sa, la);
+            apply(q, sa, la, ca, ta);
         }
     }
 
@@ -253,20 +325,20 @@ static int nf_launch_t(const NfArgs& a, hipStream_t s)
     return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
 }
 
-// tiles per wave: the smallest compiled T whose 256-workgroup grid (x2: two workgroups fit a CU) covers the rows,
+// tiles per wave: the smallest compiled T whose 256-workgroup grid (one workgroup per CU) covers the rows,
 // so that the chip is filled evenly and each workgroup stages every coupling once
 template <bool INV>
 static int nf_launch(const NfArgs& a, hipStream_t s)
 {
-    const int64_t per_t = (int64_t)2 * NF_CUS * NF_WAVES * 32;        // rows covered per unit of T
+    const int64_t per_t = (int64_t)NF_CUS * NF_WAVES * 32;            // rows covered per unit of T (one workgroup per CU)
     const int64_t need = (a.n_rows + per_t - 1) / per_t;
+    // even T keeps every MFMA in the two-tiles-per-operand form; small inputs on half the grid (one workgroup per CU)
     if (need <= 1) return nf_launch_t<INV, 1>(a, s);
     if (need <= 2) return nf_launch_t<INV, 2>(a, s);
-    if (need <= 3) return nf_launch_t<INV, 3>(a, s);
     if (need <= 4) return nf_launch_t<INV, 4>(a, s);
-    if (need <= 5) return nf_launch_t<INV, 5>(a, s);
     if (need <= 6) return nf_launch_t<INV, 6>(a, s);
-    return nf_launch_t<INV, 8>(a, s);                                 // larger inputs: more workgroups of 1024 rows
+    if (need <= 8) return nf_launch_t<INV, 8>(a, s);
+    return nf_launch_t<INV, 10>(a, s);                                // 327 680 rows = 256 workgroups x 1280; larger: more workgroups
 }
 
 extern "C" {

@@ -277,4 +277,45 @@ GLABC_HD double glabc_exp(double x)
     return (y * s1) * s2;
 }
 
+/* ---- exact, order-independent sums for GLMALA's gradient statistics (GLMALA.py:86-89) ------------------------
+ * The mean and variance of the num_grad simulated discrepancies are accumulated on data shifted by a centre c
+ * in FIXED POINT: d = x - c is an exact double (x, c are float32 values), q = rint(d * 2^40) is an exact integer for
+ * every x, c in [2^-17, 2^7] (and a deterministic rounding outside), sum(q) fits int64 and sum(q^2) a 128-bit
+ * integer for up to 65 536 terms.  Integer addition is associative, so any split of the simulations over lanes,
+ * waves or threads gives the same bits -- which is what lets a wavefront share one chain's 2*d*num_grad
+ * simulations.  (torch.mean / torch.var use their own float64 cascades; results agree to ~1e-16 relative.) */
+typedef struct { int64_t s1; uint64_t s2_lo, s2_hi; } glabc_fxsum;
+
+GLABC_HD int64_t glabc_fx_quantize(double d) { return (int64_t)__builtin_rint(d * 0x1p40); }
+
+GLABC_HD void glabc_fx_add(glabc_fxsum* a, int64_t q)
+{
+    a->s1 += q;
+    const uint64_t m = (uint64_t)(q < 0 ? -q : q);
+    const uint64_t m_lo = m & 0xffffffffu, m_hi = m >> 32;
+    /* m*m as a 128-bit number from 32-bit limbs */
+    const uint64_t ll = m_lo * m_lo, lh = m_lo * m_hi, hh = m_hi * m_hi;
+    const uint64_t mid = lh << 1;                       /* 2*lo*hi, bits 32.. ; lh < 2^47 so no overflow */
+    uint64_t lo = ll + (mid << 32);
+    uint64_t hi = hh + (mid >> 32) + (lo < ll ? 1u : 0u);
+    const uint64_t old = a->s2_lo;
+    a->s2_lo = old + lo;
+    a->s2_hi = a->s2_hi + hi + (a->s2_lo < old ? 1u : 0u);
+}
+
+GLABC_HD void glabc_fx_merge(glabc_fxsum* a, const glabc_fxsum* b)
+{
+    a->s1 += b->s1;
+    const uint64_t old = a->s2_lo;
+    a->s2_lo = old + b->s2_lo;
+    a->s2_hi = a->s2_hi + b->s2_hi + (a->s2_lo < old ? 1u : 0u);
+}
+
+/* sum(d) and sum(d^2) as doubles */
+GLABC_HD double glabc_fx_sum1(const glabc_fxsum* a) { return (double)a->s1 * 0x1p-40; }
+GLABC_HD double glabc_fx_sum2(const glabc_fxsum* a)
+{
+    return ((double)a->s2_hi * 18446744073709551616.0 + (double)a->s2_lo) * 0x1p-80;
+}
+
 #endif /* GLABC_NUMERICS_H */

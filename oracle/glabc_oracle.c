@@ -720,9 +720,9 @@ ORACLE_API void oracle_grad_noise(uint64_t seed, uint64_t chain, uint32_t step, 
 }
 
 /* numberical_gradient_logABC, GLMALA.py:46-95, for one theta (already cast to float32, :62).
- * mean / unbiased variance of the num discrepancies are accumulated in double on data shifted by
- * the first sample (torch.mean / torch.var use their own cascades; the results agree to ~1e-16
- * relative, far below anything a float32 chain value can see). */
+ * mean / unbiased variance of the num discrepancies come from exact fixed-point sums of the data shifted
+ * by the noise-free discrepancy (glabc_fxsum, include/glabc_numerics.h; torch.mean / torch.var use their own
+ * cascades; the results agree to ~1e-16 relative, far below anything a float32 chain value can see). */
 static void numerical_gradient(const glabc_model* m, const glabc_mala* p, const float* theta, uint64_t seed,
                                uint64_t chain, uint32_t step, int g, double* grad)
 {
@@ -735,19 +735,22 @@ static void numerical_gradient(const glabc_model* m, const glabc_mala* p, const 
             tp[j] = theta[j] + (j == k ? h : 0.0f);         /* :67 */
             tm[j] = theta[j] - (j == k ? h : 0.0f);         /* :68 */
         }
-        double c_p = 0.0, c_m = 0.0, s1p = 0.0, s2p = 0.0, s1m = 0.0, s2m = 0.0;
+        /* centres of the shifted sums: the discrepancy of the noise-free simulation (eps = 0) */
+        float zero[GLABC_MAX_DIM] = {0}, y0p[GLABC_MAX_DIM], y0m[GLABC_MAX_DIM];
+        model_simulate(m, tp, zero, y0p);
+        model_simulate(m, tm, zero, y0m);
+        const double c_p = (double)model_discrepancy(m, y0p), c_m = (double)model_discrepancy(m, y0m);
+        glabc_fxsum ap = {0, 0, 0}, am = {0, 0, 0};
         for (int s = 0; s < num; ++s) {
             float eps[GLABC_MAX_DIM], yp[GLABC_MAX_DIM], ym[GLABC_MAX_DIM];
             grad_noise(seed, chain, step, g, k, s, num, yd, eps);
             model_simulate(m, tp, eps, yp);                 /* :78 */
             model_simulate(m, tm, eps, ym);                 /* :82 (same noise) */
-            double dp = (double)model_discrepancy(m, yp), dm = (double)model_discrepancy(m, ym);
-            if (s == 0) { c_p = dp; c_m = dm; }
-            double ep = dp - c_p, em = dm - c_m;
-            s1p += ep; s2p += ep * ep;
-            s1m += em; s2m += em * em;
+            glabc_fx_add(&ap, glabc_fx_quantize((double)model_discrepancy(m, yp) - c_p));
+            glabc_fx_add(&am, glabc_fx_quantize((double)model_discrepancy(m, ym) - c_m));
         }
         double n = (double)num;
+        double s1p = glabc_fx_sum1(&ap), s2p = glabc_fx_sum2(&ap), s1m = glabc_fx_sum1(&am), s2m = glabc_fx_sum2(&am);
         double mu_p = c_p + s1p / n, mu_m = c_m + s1m / n;                              /* :86-87 */
         double var_p = (s2p - (s1p * s1p) / n) / (n - 1.0), var_m = (s2m - (s1m * s1m) / n) / (n - 1.0);   /* :88-89 */
         double lp = (-0.5 * glabc_log(var_p + p->eps_sq)) - ((0.5 * (mu_p * mu_p)) / (var_p + p->eps_sq));   /* :90-91 */
