@@ -45,7 +45,8 @@ enum Algo { ALGO_GLMCMC = 0, ALGO_GLOBAL = 1 };
 // exp(log_scale) == 1 (examples/Mixture.py:30,68) -- with those facts known at compile time,
 // which removes every branch from a candidate's evaluation so the scheduler can interleave
 // the independent candidates of a lane.
-enum Variant { VAR_GENERIC = 0, VAR_GAUSS_UNIT = 1 };
+// VAR_TAPE = VAR_GENERIC with the random numbers replayed from glabc_run.tape instead of Philox (one lane per chain).
+enum Variant { VAR_GENERIC = 0, VAR_GAUSS_UNIT = 1, VAR_TAPE = 2 };
 
 // ---- argument block ------------------------------------------------------------
 template <int D>
@@ -84,6 +85,11 @@ struct StepArgs {
     double* sum_theta;
     double* sum_outer;
     double* sum_jump;
+    // replayed random numbers (glabc_tape; VAR_TAPE only)
+    const float* tape_u;
+    const double* tape_r;
+    const float* tape_z;
+    int32_t tape_nprop;
 };
 
 // ---- torch.sum association over a contiguous float32 row (GLMCMC.py:82) ---------
@@ -213,7 +219,7 @@ template <int D, int YD>
 GLABC_DEV void model_simulate(const StepArgs<D, YD>& a, const float (&theta)[D], const float (&eps)[YD], float (&y)[YD])
 {
     if constexpr (YD == D) {
-        if (a.sim_kind == GLABC_SIM_ABS_GAUSS) {
+        if (D < 4 || a.sim_kind == GLABC_SIM_ABS_GAUSS) {        // D < 4: the g-and-k shape cannot occur, no run-time test
 #pragma unroll
             for (int j = 0; j < YD; ++j) {
                 float noise = a.noise_loc[j] + a.noise_scale[j] * eps[j];
@@ -343,9 +349,11 @@ GLABC_DEV void refresh_cache(const StepArgs<D, YD>& a, Chain<D, YD>& c)
 //   MH          : log(u) < ((prior'+K') - prior) - K                       GLMCMC.py:96-99
 //                 log(u) < ((((prior'+K') + q) - q') - prior) - K          GlobalMCMC.py:44-47
 template <int ALGO, int D, int YD, int N, int L, int VAR>
-GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t step, int sub, Chain<D, YD>& c)
+GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t step, int sub, Chain<D, YD>& c, int64_t tape_pos)
 {
     constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
+    constexpr bool TAPE = (VAR == VAR_TAPE);
+    static_assert(!TAPE || L == 1, "tape replay runs one lane per chain");
     constexpr int NL = (N + L - 1) / L;            // candidate slots per lane
     constexpr int HEAD = L - 1;                    // the lane with the fewest candidates draws the step head
     // When N is not a multiple of L the last slot of lane L-1 holds no candidate: the step head
@@ -363,8 +371,10 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
 #pragma unroll
             for (int q = 0; q < 4; ++q) hw[q] = (uint32_t)group_bcast_i<L, HEAD>((int)hw[q]);
         }
-        log_u = glabc_logf(glabc_uniform_f32(hw[1]));                           // GLMCMC.py:98 (u = 0 -> -inf)
-        is_global = glabc_uniform_f32(hw[0]) < a.gf;                          // GLMCMC.py:59 / GlobalMCMC.py:39
+        const float ub = TAPE ? a.tape_u[2 * tape_pos] : glabc_uniform_f32(hw[0]);
+        const float ua = TAPE ? a.tape_u[2 * tape_pos + 1] : glabc_uniform_f32(hw[1]);
+        log_u = glabc_logf(ua);                                               // GLMCMC.py:98 (u = 0 -> -inf)
+        is_global = ub < a.gf;                                                // GLMCMC.py:59 / GlobalMCMC.py:39
         if (ALGO == ALGO_GLMCMC && is_global) {
             if (c.flags & GLABC_FLAG_LOCAL) c.log_w = (c.prior + c.kern) - c.q;   // GLMCMC.py:60-64
             c.flags &= ~GLABC_FLAG_LOCAL;                                         // GLMCMC.py:65
@@ -418,6 +428,13 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         for (int i = 0; i < D; ++i) e[i] = (!GU && uni) ? glabc_uniform_f32(w[i]) : nrm[i];
 #pragma unroll
         for (int i = 0; i < YD; ++i) s[i] = nrm[D + i];
+        if constexpr (TAPE) {                       // the tape holds this candidate's draws in the same order
+            const float* tz = a.tape_z + (tape_pos * a.tape_nprop + (j < a.tape_nprop ? j : 0)) * M;
+#pragma unroll
+            for (int i = 0; i < D; ++i) e[i] = tz[i];
+#pragma unroll
+            for (int i = 0; i < YD; ++i) s[i] = tz[D + i];
+        }
 #pragma unroll
         for (int q = 0; q < D; ++q) {
             const float p0 = loc ? a.local.p0[q] : a.global.p0[q];
@@ -456,7 +473,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         }
         gather_weights<L, N, NL>(wl, w);
         const float tot = aten_rowsum<N + 1>(w);                              // GLMCMC.py:82
-        const double u_res = glabc_uniform_f64(hw[2], hw[3]);
+        const double u_res = TAPE ? a.tape_r[tape_pos] : glabc_uniform_f64(hw[2], hw[3]);
         int ig = -1;
         double run = 0.0;
 #pragma unroll

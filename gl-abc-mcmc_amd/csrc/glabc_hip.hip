@@ -466,6 +466,12 @@ static StepArgs<D, YD> pack_args(const glabc_model* m, const glabc_dist* local, 
             a.sum_outer = r->moments->sum_outer;
             a.sum_jump = r->moments->sum_jump;
         }
+        if (r->tape) {
+            a.tape_u = r->tape->u;
+            a.tape_r = r->tape->r;
+            a.tape_z = r->tape->z;
+            a.tape_nprop = r->tape->n_prop;
+        }
     }
     return a;
 }
@@ -502,7 +508,10 @@ static int check_run(const glabc_model* m, const glabc_dist* local, const glabc_
         return GLABC_ERR_ARG;
     if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
     if (r->moments && (!r->moments->sum_theta || !r->moments->sum_outer || !r->moments->sum_jump)) return GLABC_ERR_NULL;
-    if (r->tape) return GLABC_ERR_ARG;       // tape replay is implemented by the CPU checker only (for now)
+    if (r->tape) {                           // replayed random numbers: device arrays covering exactly this call
+        if (!r->tape->u || !r->tape->z || (isir && !r->tape->r)) return GLABC_ERR_NULL;
+        if (r->tape->n_prop < 1 || (isir && r->tape->n_prop < r->batch_size)) return GLABC_ERR_ARG;
+    }
     if ((uint64_t)r->step0 + (uint64_t)r->n_steps > 0xFFFFFFFFull) return GLABC_ERR_ARG;
     return GLABC_OK;
 }
@@ -532,7 +541,7 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
     if (rc) return rc;
     if (c->n_chains == 0 || r->n_steps == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int lanes = algo == ALGO_GLMCMC ? pick_lanes(r->lanes_per_chain, r->batch_size, c->n_chains) : 1;
+    const int lanes = (algo == ALGO_GLMCMC && !r->tape) ? pick_lanes(r->lanes_per_chain, r->batch_size, c->n_chains) : 1;
     if (m->sim_kind == GLABC_SIM_GK) {
         rc = launch_sampler_dim<4, 8>(algo, r->batch_size, lanes, pack_args<4, 8>(m, local, global, c, r), s);
     } else {

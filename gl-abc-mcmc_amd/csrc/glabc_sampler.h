@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D, YD> a)
 #pragma unroll
         for (int j = 0; j < D; ++j) prev[j] = c.theta[j];
 
-        const bool moved = chain_step<ALGO, D, YD, N, L, VAR>(a, rng, step, sub, c);
+        const bool moved = chain_step<ALGO, D, YD, N, L, VAR>(a, rng, step, sub, c, i * (int64_t)a.n_steps + t);
         c.n_moves += moved ? 1u : 0u;
 
         if (hist && writer) {                                       // Theta_Re[i,:] = Theta_old, GLMCMC.py:89,104

@@ -24,7 +24,12 @@ static int launch_one(const StepArgs<D, YD>& a, hipStream_t s)
 {
     const int64_t lanes = a.n_chains * L;
     const unsigned grid = (unsigned)((lanes + BLOCK - 1) / BLOCK);
-    if (YD == D && gauss_unit<D, YD>(a))
+    if (a.tape_u) {
+        if constexpr (L == 1)
+            hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, 1, VAR_TAPE>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else
+            return GLABC_ERR_ARG;
+    } else if (YD == D && gauss_unit<D, YD>(a))
         hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, L, (YD == D ? VAR_GAUSS_UNIT : VAR_GENERIC)>), dim3(grid), dim3(BLOCK), 0, s, a);
     else
         hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, L, VAR_GENERIC>), dim3(grid), dim3(BLOCK), 0, s, a);

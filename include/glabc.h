@@ -133,8 +133,10 @@ typedef struct glabc_moments {
 } glabc_moments;
 
 /* Replayed random numbers (tests, common-random-number studies): when
- * glabc_run.tape is non-NULL the kernel reads its draws from here instead of
- * Philox.  Layout is chain-outermost, as recorded by tests/golden/make_golden.py. */
+ * glabc_run.tape is non-NULL glabc_glmcmc_steps / glabc_globalmcmc_steps read their draws
+ * from here (device arrays covering exactly the call's n_steps) instead of Philox.
+ * Layout is chain-outermost, as recorded by tests/golden/make_golden.py.  (GLMALA and the
+ * GLMCMC_NF entry points do not take a tape.) */
 typedef struct glabc_tape {
     const float* u;                /* [n_chains][n_steps][2]  (branch, accept) f32 in [0,1) */
     const double* r;               /* [n_chains][n_steps]     resampling uniform f64 in [0,1) */

@@ -74,6 +74,38 @@ def test_hip_reproduces_reference_chains(hip, name):
     assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
 
 
+@pytest.mark.parametrize("name", [n for n in SAMPLER_GOLDENS if "tape" in n])
+def test_hip_replays_stored_tapes(hip, name):
+    """glabc_run.tape on the GPU: the stored-tape goldens (NumPy-generated numbers, independent of the Philox
+    specification) replayed through the kernels give the reference's chains bit for bit."""
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import engine
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, local, glob = descriptors(cfg, g)
+    algo = str(g["algo"])
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(g["theta0"]), torch.from_numpy(g["y0"]), dev)
+    if algo == "glmcmc":
+        engine.init_weights(model, glob, chains)
+    T = cfg["T"]
+    u = torch.from_numpy(np.ascontiguousarray(g["tape_u"])).to(dev)
+    r = torch.from_numpy(np.ascontiguousarray(g["tape_r"])).to(dev)
+    z = torch.from_numpy(np.ascontiguousarray(g["tape_z"])).to(dev)
+    tape = A.Tape(u.data_ptr(), r.data_ptr(), z.data_ptr(), g["tape_z"].shape[2], 0)
+    hist = torch.empty(T, 2, chains.n, dtype=torch.float32, device=dev)
+    run = A.Run()
+    run.seed, run.step0, run.n_steps, run.global_frequency, run.batch_size = 0, 1, T, cfg["gf"], cfg["N"]
+    run.history, run.hist_stride, run.tape = hist.data_ptr(), chains.n, C.pointer(tape)
+    cs = chains.struct()
+    fn = hip.glabc_glmcmc_steps if algo == "glmcmc" else hip.glabc_globalmcmc_steps
+    assert fn(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run), None) == 0
+    torch.cuda.synchronize()
+    got = np.concatenate([g["theta0"][None], hist.cpu().numpy().transpose(0, 2, 1)], axis=0)
+    same = bits(got) == bits(g["chains"])
+    assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
+
+
 # ---------------------------------------------------------------------------------- (2)
 CASES = [
     # algo, d, N, gf, eps, local, global, chains, T
