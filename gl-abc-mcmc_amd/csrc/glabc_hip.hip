@@ -357,6 +357,35 @@ __global__ void __launch_bounds__(64) nf_step_kernel(const PoolArgs<D> p)
     p.kk[i] = kk;
     if (a.n_moves) a.n_moves[i] = n_moves + (moved ? 1u : 0u);
 }
+
+// ---- Gamma.log_prob, distribution.py:123-137 (float64) ----------------------------------------------------
+struct GammaArgs {
+    glabc_gamma g;
+    const double* z;
+    double* out;
+    int64_t n;
+};
+
+__global__ void __launch_bounds__(256) gamma_log_prob_kernel(const GammaArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    double acc = 0.0;
+    for (int j = 0; j < a.g.dim; ++j) {
+        const double x = a.z[i * a.g.dim + j] / a.g.scale[j];
+        double lp;
+        if (x >= 0.0) {                                    // scipy's support of gamma is closed at 0
+            const double am1 = a.g.shape[j] - 1.0;
+            const double xl = am1 == 0.0 ? 0.0 : am1 * glabc_log(x);               // scipy.special.xlogy
+            const double p = glabc_exp((xl - x) - a.g.gammaln[j]) / a.g.scale[j];     // gamma.pdf
+            lp = p > 0.0 ? glabc_log(p) : -__builtin_inf();                         // distribution.py:136
+        } else {
+            lp = -__builtin_inf();
+        }
+        acc = j == 0 ? lp : acc + lp;                                               // torch.sum(dim=1), distribution.py:137
+    }
+    a.out[i] = acc;
+}
 }  // namespace glabc
 
 // =================================================================================================
@@ -731,6 +760,24 @@ __attribute__((visibility("default"))) int glabc_glmcmc_nf_step(const glabc_mode
 }
 
 }  // extern "C"
+
+extern "C" __attribute__((visibility("default"))) int glabc_gamma_log_prob(const glabc_gamma* dist, const double* z, int64_t n,
+                                                                           double* out, void* stream)
+{
+    if (!dist || !z || !out) return GLABC_ERR_NULL;
+    if (dist->dim < 1 || dist->dim > 3) return GLABC_ERR_DIM;        // < 4 terms: torch's float64 row sum is sequential
+    if (n < 0) return GLABC_ERR_ARG;
+    for (int j = 0; j < dist->dim; ++j)
+        if (!(dist->shape[j] > 0.0) || !(dist->scale[j] > 0.0) || !std::isfinite(dist->gammaln[j])) return GLABC_ERR_ARG;
+    if (n == 0) return GLABC_OK;
+    GammaArgs a;
+    a.g = *dist;
+    a.z = z;
+    a.out = out;
+    a.n = n;
+    hipLaunchKernelGGL(gamma_log_prob_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return finish_launch();
+}
 
 template <int OP>
 static int launch_rowwise(const RowArgs& a, hipStream_t s)

@@ -217,25 +217,53 @@ GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step
         glabc_fxsum ap, am;
         ap.s1 = am.s1 = 0;
         ap.s2_lo = ap.s2_hi = am.s2_lo = am.s2_hi = 0;
+        // one simulation of coordinate k with noise index s
+        auto one_sim = [&](const float (&eps)[D]) {
+            float yp[D], ym[D];
+            model_simulate<D>(a, tp, eps, yp);                          // GLMALA.py:78
+            model_simulate<D>(a, tm, eps, ym);                          // GLMALA.py:82 (same noise)
+            glabc_fx_add(&ap, glabc_fx_quantize((double)model_discrepancy<D>(a, yp) - c_p));
+            glabc_fx_add(&am, glabc_fx_quantize((double)model_discrepancy<D>(a, ym) - c_m));
+        };
+        if constexpr (D == 2) {
+            // a Philox block holds the four normals of TWO consecutive simulations: lanes walk blocks, not simulations
+            const int64_t first = (int64_t)k * num;                     // global simulation index of s = 0
+            const int64_t b_lo = first >> 1, b_hi = (first + num - 1) >> 1;
+            const int n_blocks = (int)(b_hi - b_lo + 1);
+            const int brounds = (n_blocks + G - 1) / G;
 #pragma unroll 1
-        for (int rd = 0; rd < rounds; ++rd) {
-            const int s = rd * G + sub;
-            if (s < num) {
-                float eps[D], yp[D], ym[D];
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    const int64_t nn = ((int64_t)k * num + s) * D + j;
-                    glabc_u32x4 blk = glabc_philox4x32_10(r2.c0, r2.c1, step, GRAD_BASE + (uint32_t)g * GRAD_STRIDE + (uint32_t)(nn >> 2),
+            for (int rd = 0; rd < brounds; ++rd) {
+                const int bi = rd * G + sub;
+                if (bi < n_blocks) {
+                    const int64_t b = b_lo + bi;
+                    glabc_u32x4 blk = glabc_philox4x32_10(r2.c0, r2.c1, step, GRAD_BASE + (uint32_t)g * GRAD_STRIDE + (uint32_t)b,
                                                           r2.k0, r2.k1);
-                    const int p = (int)((nn & 3) >> 1);
-                    float z0, z1;
-                    glabc_normal_pair(p ? blk.v[2] : blk.v[0], p ? blk.v[3] : blk.v[1], &z0, &z1);
-                    eps[j] = (nn & 1) ? z1 : z0;
+                    float e0[2], e1[2];
+                    glabc_normal_pair(blk.v[0], blk.v[1], &e0[0], &e0[1]);
+                    glabc_normal_pair(blk.v[2], blk.v[3], &e1[0], &e1[1]);
+                    const int64_t s0 = 2 * b - first, s1 = s0 + 1;      // simulation indices within coordinate k
+                    if (s0 >= 0 && s0 < num) one_sim(e0);
+                    if (s1 >= 0 && s1 < num) one_sim(e1);
                 }
-                model_simulate<D>(a, tp, eps, yp);                      // GLMALA.py:78
-                model_simulate<D>(a, tm, eps, ym);                      // GLMALA.py:82 (same noise)
-                glabc_fx_add(&ap, glabc_fx_quantize((double)model_discrepancy<D>(a, yp) - c_p));
-                glabc_fx_add(&am, glabc_fx_quantize((double)model_discrepancy<D>(a, ym) - c_m));
+            }
+        } else {
+#pragma unroll 1
+            for (int rd = 0; rd < rounds; ++rd) {
+                const int s = rd * G + sub;
+                if (s < num) {
+                    float eps[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const int64_t nn = ((int64_t)k * num + s) * D + j;
+                        glabc_u32x4 blk = glabc_philox4x32_10(r2.c0, r2.c1, step,
+                                                              GRAD_BASE + (uint32_t)g * GRAD_STRIDE + (uint32_t)(nn >> 2), r2.k0, r2.k1);
+                        const int p = (int)((nn & 3) >> 1);
+                        float z0, z1;
+                        glabc_normal_pair(p ? blk.v[2] : blk.v[0], p ? blk.v[3] : blk.v[1], &z0, &z1);
+                        eps[j] = (nn & 1) ? z1 : z0;
+                    }
+                    one_sim(eps);
+                }
             }
         }
         for (int mm = G >> 1; mm >= 1; mm >>= 1) {                      // merge the group's partial sums (exact integers)

@@ -118,6 +118,17 @@ class Pool(C.Structure):
     ]
 
 
+class GammaDesc(C.Structure):
+    """struct glabc_gamma"""
+    _fields_ = [
+        ("dim", C.c_int32),
+        ("reserved", C.c_int32),
+        ("shape", C.c_double * MAX_DIM),
+        ("scale", C.c_double * MAX_DIM),
+        ("gammaln", C.c_double * MAX_DIM),
+    ]
+
+
 class Moments(C.Structure):
     """struct glabc_moments"""
     _fields_ = [
@@ -170,6 +181,7 @@ ENTRY_POINTS = {
     "glabc_glmcmc_nf_step": (C.c_int, [_P(Model), _P(Dist), _P(Pool), _P(Chains), _P(Run), C.c_void_p]),
     "glabc_init_weights": (C.c_int, [_P(Model), _P(Dist), _P(Chains), C.c_void_p]),
     "glabc_dist_log_prob": (C.c_int, [_P(Dist), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_gamma_log_prob": (C.c_int, [_P(GammaDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_prior_log_prob": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_discrepancy": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_log_kernel": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -124,7 +124,32 @@ class Gamma(BaseDistribution):
         z = torch.tensor(gamma.rvs(self.Shape, scale=1 / self.Rate, size=size))
         return z, self.log_prob(z)
 
+    def descriptor(self):
+        """glabc_gamma (include/glabc.h): float64 shape, scale = 1/rate as distribution.py:133 forms it, gammaln(shape)"""
+        from scipy.special import gammaln
+        shape = np.asarray(self.Shape).reshape(-1)
+        scale = np.asarray(1 / self.Rate).reshape(-1)
+        d = _capi.GammaDesc()
+        d.dim = int(shape.size)
+        if d.dim > 3:
+            raise ValueError("Gamma on the GPU supports up to 3 dimensions")
+        # scipy evaluates gammaln in the dtype of the shape parameter: the reference stores Shape as the float32
+        # array Shape.numpy() (distribution.py:103), so gammaln(shape) is a float32 number there
+        gl = np.asarray(gammaln(self.Shape)).reshape(-1)
+        for j in range(d.dim):
+            d.shape[j], d.scale[j], d.gammaln[j] = float(shape[j]), float(scale[j]), float(gl[j])
+        return d
+
     def log_prob(self, z, context=None):
+        if z.is_cuda:
+            desc = self.descriptor()
+            zz = z.detach().to(torch.float64).reshape(z.shape[0], -1).contiguous()
+            out = torch.empty(zz.shape[0], dtype=torch.float64, device=z.device)
+            stream = torch.cuda.current_stream(z.device).cuda_stream
+            with torch.cuda.device(z.device):
+                _capi.check(_capi.lib().glabc_gamma_log_prob(C.byref(desc), zz.data_ptr(), zz.shape[0], out.data_ptr(),
+                                                             C.c_void_p(stream)), "Gamma.log_prob")
+            return out
         from scipy.stats import gamma
         p = gamma.pdf(z.cpu().numpy(), self.Shape, scale=1 / self.Rate)
         with np.errstate(divide="ignore"):

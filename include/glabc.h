@@ -259,6 +259,21 @@ int glabc_init_weights(const glabc_model* model, const glabc_dist* importance,
 /* distribution.py:176-181 / 81-86 / 123-137: log_prob of n row-major points z[n][dim] -> out[n]. */
 int glabc_dist_log_prob(const glabc_dist* dist, const float* z, int64_t n, float* out, void* stream);
 
+/* Gamma.log_prob, distribution.py:123-137: float64, log(scipy.stats.gamma.pdf(z, shape, scale=1/rate)) with -inf where
+ * the pdf is 0 (it underflows earlier than a logpdf would -- reproduced), summed over the dimensions.
+ *   pdf_j = exp((shape_j - 1) log(x) - x - gammaln(shape_j)) / scale_j,  x = z_j / scale_j,  0 outside x > 0
+ * gammaln[] is supplied by the caller (scipy.special.gammaln(shape) on the host; a constant of the distribution).
+ * z[n][dim] row-major float64 -> out[n] float64. */
+typedef struct glabc_gamma {
+    int32_t dim;
+    int32_t reserved;
+    double shape[GLABC_MAX_DIM];
+    double scale[GLABC_MAX_DIM];   /* 1/rate as the reference forms it (float32 reciprocal, distribution.py:133) */
+    double gammaln[GLABC_MAX_DIM];
+} glabc_gamma;
+
+int glabc_gamma_log_prob(const glabc_gamma* dist, const double* z, int64_t n, double* out, void* stream);
+
 /* Model callbacks on n row-major points (Mixture.py:28-45): used by the host
  * mirror's Model class and by the parity tests. */
 int glabc_model_prior_log_prob(const glabc_model* model, const float* theta, int64_t n, float* out, void* stream);

@@ -148,6 +148,30 @@ ORACLE_API int oracle_dist_log_prob(const glabc_dist* dist, const float* z, int6
     return 0;
 }
 
+/* Gamma.log_prob, distribution.py:123-137 (float64; scipy.stats.gamma.pdf restated: exp(xlogy(a-1, x) - x - gammaln(a)) / scale) */
+ORACLE_API int oracle_gamma_log_prob(const glabc_gamma* g, const double* z, int64_t n, double* out)
+{
+    if (!g || !z || !out) return GLABC_ERR_NULL;
+    if (g->dim < 1 || g->dim > 3) return GLABC_ERR_DIM;
+    for (int64_t i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < g->dim; ++j) {
+            double x = z[i * g->dim + j] / g->scale[j], lp;
+            if (x >= 0.0) {                                /* scipy's support of gamma is closed at 0 */
+                double am1 = g->shape[j] - 1.0;
+                double xl = am1 == 0.0 ? 0.0 : am1 * glabc_log(x);
+                double p = glabc_exp((xl - x) - g->gammaln[j]) / g->scale[j];
+                lp = p > 0.0 ? glabc_log(p) : -INFINITY;
+            } else {
+                lp = -INFINITY;
+            }
+            acc = j == 0 ? lp : acc + lp;
+        }
+        out[i] = acc;
+    }
+    return 0;
+}
+
 /* forward() with the noise supplied by the caller: noise[n][dim] -> z[n][dim], log_p[n]. */
 ORACLE_API int oracle_dist_forward(const glabc_dist* dist, const float* noise, int64_t n, float* z, float* log_p)
 {

@@ -527,3 +527,16 @@ def test_full_size_bit_parity_and_posterior(hip, oracle):
     assert ok.mean() > 0.97
     assert abs(e_hist[ok].mean() - e_mom[ok].mean()) / e_hist[ok].mean() < 1e-3
     assert 0.001 < e_hist[ok].mean() < 1.0
+
+
+def test_gamma_log_prob_on_gpu(hip, oracle, prim):
+    from glabcmcmc_amd import distribution
+    for tag in ("a", "b", "c"):
+        g = distribution.Gamma(torch.from_numpy(prim["gm_%s_shape" % tag]), torch.from_numpy(prim["gm_%s_rate" % tag]))
+        d = g.descriptor()
+        z = prim["gm_%s_z" % tag]
+        o = np.empty(len(z))
+        assert oracle.oracle_gamma_log_prob(C.byref(d), z.ctypes.data, len(z), o.ctypes.data) == 0
+        got = g.log_prob(torch.from_numpy(z).cuda()).cpu().numpy()
+        assert got.dtype == np.float64
+        assert np.array_equal(got.view(np.uint64), o.view(np.uint64)), tag

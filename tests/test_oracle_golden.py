@@ -246,3 +246,24 @@ def test_glmala_gradient_matches_reference(oracle):
                                                 int(g["step"][i]), 1, out.ctypes.data) == 0
         worst = max(worst, np.max(np.abs(out - g["grad"][i]) / np.maximum(1.0, np.abs(g["grad"][i]))))
     assert worst < 1e-11, worst
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gamma_log_prob(oracle, prim, tag):
+    """Gamma.log_prob (distribution.py:123-137, SciPy float64): same -inf pattern (negative z, pdf underflow, z = 0),
+    1e-12 where the pdf is a normal double; in the subnormal tail log(pdf) itself only has a few significant bits."""
+    import torch
+    from glabcmcmc_amd import distribution
+    g = distribution.Gamma(torch.from_numpy(prim["gm_%s_shape" % tag]), torch.from_numpy(prim["gm_%s_rate" % tag]))
+    d = g.descriptor()
+    z, ref = prim["gm_%s_z" % tag], prim["gm_%s_log_prob" % tag]
+    out = np.empty(len(z))
+    assert oracle.oracle_gamma_log_prob(C.byref(d), z.ctypes.data, len(z), out.ctypes.data) == 0
+    assert np.array_equal(np.isneginf(out), np.isneginf(ref)) and np.array_equal(np.isposinf(out), np.isposinf(ref))
+    fin = np.isfinite(ref)
+    normal = fin & (ref > -650)
+    assert normal.sum() > 200
+    assert np.max(np.abs(out[normal] - ref[normal]) / np.maximum(1, np.abs(ref[normal]))) < 1e-12
+    assert np.max(np.abs(out[fin] - ref[fin]) / np.maximum(1, np.abs(ref[fin]))) < 1e-6
+    # host mirror on CPU tensors = the reference's own SciPy path
+    assert np.array_equal(g.log_prob(torch.from_numpy(z)).numpy(), ref)
