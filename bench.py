@@ -254,18 +254,23 @@ def main():
         esjd_all = stats["esjd"]
         ok = torch.isfinite(esjd_all)
         # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
-        # read correction applied) for exactly this configuration: profiles/r01_b_pmc_summary.json
+        # read correction applied) for exactly this configuration: profiles/r01_d_pmc_summary.json
         traffic, valu = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_b_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_d_pmc_summary.json")) as f:
                 pmc = json.load(f)
             if args.workload == "glmcmc" and pmc["config"] == {"chains": n, "iters_per_launch": K,
                                                                "history": not args.no_history}:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]["total"]
-                valu = {"source": "profiles/r01_b_pmc_summary.json (rocprofv3 --pmc, round 1)",
-                        "valu_insts_per_wave_step": pmc["derived"]["valu_insts_per_wave_step"],
+                per_step = pmc["derived"]["valu_insts_per_wave_step"]
+                wave_insts_per_s = per_step * (n / 64.0) * K / (kernel_ms * 1e-3)      # live kernel time x counted instructions
+                valu = {"source": "profiles/r01_d_pmc_summary.json (rocprofv3 --pmc, round 1) + this run's kernel time",
+                        "valu_insts_per_wave_step": per_step,
                         "valu_active_fraction": pmc["derived"]["valu_active_fraction"],
-                        "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"]}
+                        "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
+                        "wave_insts_per_s": wave_insts_per_s,
+                        "issue_peak_wave_insts_per_s": 1024 * 2.4e9 / 2,                 # 1024 SIMDs, one wave64 VALU op per 2 cycles
+                        "issue_frac": wave_insts_per_s / (1024 * 2.4e9 / 2)}
         except (OSError, KeyError, ValueError):
             pass
         out = {
