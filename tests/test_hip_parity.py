@@ -540,3 +540,50 @@ def test_gamma_log_prob_on_gpu(hip, oracle, prim):
         got = g.log_prob(torch.from_numpy(z).cuda()).cpu().numpy()
         assert got.dtype == np.float64
         assert np.array_equal(got.view(np.uint64), o.view(np.uint64)), tag
+
+
+def test_checkpoint_resume_is_exact(hip, tmp_path):
+    """save the state + Philox position mid-run, reload, continue: identical bits to the
+    uninterrupted run (GLMCMC state and streaming sums; GLMALA's float64 state as well)."""
+    from glabcmcmc_amd import checkpoint, engine
+    cfg = dict(epsilon=0.3, tau=0.3, num_grad=8, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(12)
+    n, T1, T2, N, seed = 500, 60, 45, 5, 99
+    theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+    y0 = np.abs(theta0).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    # uninterrupted
+    full, cfull, mfull = hip_run("glmcmc", model, local, glob, theta0, y0, T1 + T2, seed, 0.8, N, moments=True)
+    # interrupted at T1
+    _, c1, m1 = hip_run("glmcmc", model, local, glob, theta0, y0, T1, seed, 0.8, N, moments=True)
+    checkpoint.save(str(tmp_path / "ck.pt"), c1, seed, 1 + T1, moments=m1, extra={"note": "glmcmc"})
+    c2, seed2, step2, m2, extra = checkpoint.load(str(tmp_path / "ck.pt"), dev)
+    assert (seed2, step2, extra["note"]) == (seed, 1 + T1, "glmcmc")
+    hist2 = torch.empty(T2, 2, n, dtype=torch.float32, device=dev)
+    engine.run_steps("glabc_glmcmc_steps", model, local, glob, c2, T2, step2, seed2, 0.8, N, history=hist2, moments=m2)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(hist2.cpu().numpy()), bits(full[T1:]))
+    assert np.array_equal(m2.sum_jump.cpu().numpy(), mfull.sum_jump.cpu().numpy()) and m2.steps == T1 + T2
+    assert np.array_equal(bits(c2.log_w.cpu().numpy()), bits(cfull.log_w.cpu().numpy()))
+    # GLMALA
+    mala = mala_params(cfg)
+    full, cfull, _ = hip_glmala(model, glob, mala, theta0, y0, T1 + T2, seed, 0.5, N)
+    _, c1, _ = hip_glmala(model, glob, mala, theta0, y0, T1, seed, 0.5, N)
+    checkpoint.save(str(tmp_path / "ck2.pt"), c1, seed, 1 + T1)
+    c2, seed2, step2, _, _ = checkpoint.load(str(tmp_path / "ck2.pt"), dev)
+    hist2 = torch.empty(T2, 2, n, dtype=torch.float32, device=dev)
+    engine.run_glmala_steps(model, glob, mala, c2, T2, step2, seed2, 0.5, N, history=hist2)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(hist2.cpu().numpy()), bits(full[T1:]))
+    assert np.array_equal(c2.theta64.cpu().numpy(), cfull.theta64.cpu().numpy())
+    assert np.array_equal(c2.grad.cpu().numpy(), cfull.grad.cpu().numpy())
+
+
+def test_global_frequency_sweep(hip):
+    """SURVEY 8(f) f-2 (examples/Mixture_hyper.py): the sweep runs, ESJD of the iSIR mixes beats pure local moves."""
+    from glabcmcmc_amd.examples.Mixture_hyper import sweep
+    out = sweep(num_ite=400, chains_per_cell=1024, frequencies=[0, 0.5, 0.9, 1], seeds=[1, 2], verbose=False)
+    assert out["esjd"].shape == (2, 4) and np.isfinite(out["resjd_mean"]).all()
+    assert out["best_gf"] in (0, 0.5, 0.9, 1)
+    assert out["esjd"][:, 2].mean() > out["esjd"][:, 0].mean()
