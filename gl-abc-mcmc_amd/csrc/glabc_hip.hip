@@ -266,6 +266,60 @@ __global__ void __launch_bounds__(256) pool_weights_kernel(const PoolArgs<D> p)
     p.w_out[r] = (v != v) ? 0.0f : v;                                                   // :83-85
 }
 
+// BaseDistribution.forward on the device (distribution.py:165-173, 73-78)
+template <int D>
+struct ForwardArgs {
+    DistArgs<D> g;
+    int64_t n, row0;
+    uint32_t seed_lo, seed_hi;
+    float* z;
+    float* log_p;
+};
+
+template <int D>
+__global__ void __launch_bounds__(256) dist_forward_kernel(const ForwardArgs<D> a)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n) return;
+    const uint64_t gid = (uint64_t)(a.row0 + r);
+    constexpr int NB = (D + 3) / 4;
+    float e[4 * NB], noise[D];
+    const bool uni = a.g.kind == GLABC_DIST_UNIFORM;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, (uint32_t)b, a.seed_lo, a.seed_hi);
+        float n0, n1, n2, n3;
+        glabc_normal_pair(w.v[0], w.v[1], &n0, &n1);
+        glabc_normal_pair(w.v[2], w.v[3], &n2, &n3);
+        e[4 * b] = uni ? glabc_uniform_f32(w.v[0]) : n0;
+        e[4 * b + 1] = uni ? glabc_uniform_f32(w.v[1]) : n1;
+        e[4 * b + 2] = uni ? glabc_uniform_f32(w.v[2]) : n2;
+        e[4 * b + 3] = uni ? glabc_uniform_f32(w.v[3]) : n3;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        noise[j] = e[j];
+        a.z[j * a.n + r] = a.g.p0[j] + a.g.p2[j] * e[j];                                // distribution.py:170 / :77
+    }
+    a.log_p[r] = dist_forward_log_p<D>(a.g, noise);
+}
+
+// AGLMCMC.py:104-109 / 199-204: pool weights from stored discrepancies under the threshold in a.kern_*
+template <int D>
+__global__ void __launch_bounds__(256) train_weights_kernel(const PoolArgs<D> p)
+{
+    const StepArgs<D>& a = p.s;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= p.n_rows) return;
+    float th[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) th[j] = p.theta[j * p.n_rows + r];
+    const float e = (p.x[r] - 0.0f) / a.kern_scale;                                     // Mixture.py:50-52
+    const float k = a.kern_c0 - (a.kern_log_scale + 0.5f * (e * e));
+    const float v = glabc_expf((dist_log_prob<D>(a.prior, th) + k) - p.log_q[r]);       // AGLMCMC.py:200-201
+    p.w_out[r] = (v != v) ? 0.0f : v;
+}
+
 template <int D, int N>
 __global__ void __launch_bounds__(64) nf_step_kernel(const PoolArgs<D> p)
 {
@@ -724,6 +778,63 @@ __attribute__((visibility("default"))) int glabc_pool_weights(const glabc_model*
     default: return GLABC_ERR_DIM;
     }
 #undef GLABC_POOLW
+}
+
+__attribute__((visibility("default"))) int glabc_dist_forward(const glabc_dist* dist, int64_t n, uint64_t seed, int64_t row0,
+                                                              float* z_out, float* log_p_out, void* stream)
+{
+    if (!dist) return GLABC_ERR_NULL;
+    int rc = check_dist(dist, dist->dim);
+    if (rc) return rc;
+    if (n < 0 || row0 < 0) return GLABC_ERR_ARG;
+    if (n == 0) return GLABC_OK;
+    if (!z_out || !log_p_out) return GLABC_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+#define GLABC_FWD(d)                                                          \
+    case d: {                                                                 \
+        ForwardArgs<d> a;                                                     \
+        std::memset(&a, 0, sizeof a);                                         \
+        a.g = pack_dist<d>(dist);                                             \
+        a.n = n; a.row0 = row0; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); \
+        a.z = z_out; a.log_p = log_p_out;                                     \
+        hipLaunchKernelGGL((dist_forward_kernel<d>), dim3(grid_for(n, 256)), dim3(256), 0, s, a); \
+        return finish_launch();                                               \
+    }
+    switch (dist->dim) {
+        GLABC_FWD(1) GLABC_FWD(2) GLABC_FWD(3) GLABC_FWD(4)
+    default: return GLABC_ERR_DIM;
+    }
+#undef GLABC_FWD
+}
+
+__attribute__((visibility("default"))) int glabc_kde_train_weights(const glabc_model* model, const float* theta, const float* dis,
+                                                                   const float* log_q, int64_t n, float* w_out, void* stream)
+{
+    int rc = check_model(model);
+    if (rc) return rc;
+    if (!theta || !dis || !log_q || !w_out) return GLABC_ERR_NULL;
+    if (n < 0) return GLABC_ERR_ARG;
+    if (n == 0) return GLABC_OK;
+    glabc_chains dummy;
+    std::memset(&dummy, 0, sizeof dummy);
+    glabc_run r;
+    std::memset(&r, 0, sizeof r);
+    hipStream_t s = (hipStream_t)stream;
+#define GLABC_TRAINW(d)                                                       \
+    case d: {                                                                 \
+        PoolArgs<d> p;                                                        \
+        std::memset(&p, 0, sizeof p);                                         \
+        p.s = pack_args<d>(model, nullptr, &model->prior, &dummy, &r);        \
+        p.theta = theta; p.x = dis; p.log_q = log_q; p.w_out = w_out;         \
+        p.n_rows = n;                                                         \
+        hipLaunchKernelGGL((train_weights_kernel<d>), dim3(grid_for(n, 256)), dim3(256), 0, s, p); \
+        return finish_launch();                                               \
+    }
+    switch (model->theta_dim) {
+        GLABC_TRAINW(1) GLABC_TRAINW(2) GLABC_TRAINW(3) GLABC_TRAINW(4)
+    default: return GLABC_ERR_DIM;
+    }
+#undef GLABC_TRAINW
 }
 
 __attribute__((visibility("default"))) int glabc_glmcmc_nf_step(const glabc_model* model, const glabc_dist* local,

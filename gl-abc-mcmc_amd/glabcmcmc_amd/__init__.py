@@ -18,7 +18,8 @@ from .GLMCMC import GLMCMC
 from .AGLMCMC import AGLMCMC
 from .GLMCMC_NFs import GLMCMC_NF
 from .ESJD import esjd
+from .kernel_density import KernelDensity
 from . import _capi, distribution, engine, flows
 
 __all__ = ["GlobalMCMC", "MCMCRunner", "Uniform", "Gamma", "DiagGaussian", "GaussianMixture", "GLMALA", "GLMCMC",
-           "AGLMCMC", "GLMCMC_NF", "esjd", "distribution", "engine"]
+           "AGLMCMC", "GLMCMC_NF", "esjd", "KernelDensity", "distribution", "engine"]

@@ -118,6 +118,21 @@ class Pool(C.Structure):
     ]
 
 
+class Kde(C.Structure):
+    """struct glabc_kde"""
+    _fields_ = [
+        ("dim", C.c_int32),
+        ("reserved", C.c_int32),
+        ("n_samples", C.c_int64),
+        ("x", C.c_void_p),
+        ("log_w", C.c_void_p),
+        ("cum_q", C.c_void_p),
+        ("bandwidth", C.c_float * MAX_DIM),
+        ("sum_log_bw", C.c_float),
+        ("c_2pi", C.c_float),
+    ]
+
+
 class GammaDesc(C.Structure):
     """struct glabc_gamma"""
     _fields_ = [
@@ -179,8 +194,14 @@ ENTRY_POINTS = {
     "glabc_pool_weights": (C.c_int, [_P(Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "glabc_glmcmc_nf_step": (C.c_int, [_P(Model), _P(Dist), _P(Pool), _P(Chains), _P(Run), C.c_void_p]),
+    "glabc_kde_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "glabc_kde_log_prob": (C.c_int, [_P(Kde), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_kde_sample": (C.c_int, [_P(Kde), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_kde_train_weights": (C.c_int, [_P(Model), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_init_weights": (C.c_int, [_P(Model), _P(Dist), _P(Chains), C.c_void_p]),
     "glabc_dist_log_prob": (C.c_int, [_P(Dist), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_dist_forward": (C.c_int, [_P(Dist), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "glabc_gamma_log_prob": (C.c_int, [_P(GammaDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_prior_log_prob": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_discrepancy": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -259,6 +259,13 @@ int glabc_init_weights(const glabc_model* model, const glabc_dist* importance,
 /* distribution.py:176-181 / 81-86 / 123-137: log_prob of n row-major points z[n][dim] -> out[n]. */
 int glabc_dist_log_prob(const glabc_dist* dist, const float* z, int64_t n, float* out, void* stream);
 
+/* BaseDistribution.forward(n), distribution.py:165-173 / 73-78, drawn on the device: row r (global id row0 + r)
+ * takes its dim variates from Philox(seed; id, 0, b), b = 0..ceil(dim/4)-1 -- DiagGaussian: Box-Muller pairs of
+ * words (2i, 2i+1), z = loc + exp(log_scale)*eps; Uniform: one float32 uniform per word, z = low + (high-low)*u --
+ * and returns forward()'s log_p.  z_out is dimension-major [dim][n]. */
+int glabc_dist_forward(const glabc_dist* dist, int64_t n, uint64_t seed, int64_t row0, float* z_out, float* log_p_out,
+                       void* stream);
+
 /* Gamma.log_prob, distribution.py:123-137: float64, log(scipy.stats.gamma.pdf(z, shape, scale=1/rate)) with -inf where
  * the pdf is 0 (it underflows earlier than a logpdf would -- reproduced), summed over the dimensions.
  *   pdf_j = exp((shape_j - 1) log(x) - x - gammaln(shape_j)) / scale_j,  x = z_j / scale_j,  0 outside x > 0
@@ -290,6 +297,51 @@ int glabc_esjd(const float* history, int64_t n_rows, int32_t theta_dim, int64_t 
  * iterations): esjd[c] = det(sum_jump_c / n_steps)^(1/theta_dim).  No history needed. */
 int glabc_moments_esjd(const glabc_moments* moments, int64_t n_steps, int32_t theta_dim, int64_t n_chains,
                        int64_t stride, float* esjd_out, void* stream);
+
+/* ---- KernelDensity, the adaptive proposal of AGLMCMC (kernel_density.py:4-177) --------
+ * A weighted Gaussian KDE over n_samples centres.  All arrays are device pointers; x is dimension-major.
+ *
+ * glabc_kde_fit (kernel_density.py:70-94, weighted_std :40-68): weights = w_raw / sum(w_raw) (w_raw NULL: 1/n);
+ * bandwidth = h * weighted_std(x, weights, unbiased) with h the Silverman / Scott factor the host formed in Python
+ * floats (:24-33), or bw_fixed[dim] (host array) when the caller passes an explicit bandwidth (then h is ignored).
+ * Sums are float64 in a fixed order (256 strided partials, then a binary tree) instead of torch.sum's float32
+ * cascade; everything else is the reference's float32 arithmetic.  Outputs: weights_out[n], log_w_out[n] =
+ * log(weights + 1e-10) (:125), wq_out[n] = rint(weights * 2^40) (the integer weights glabc_kde_sample draws
+ * from; the caller turns them into inclusive prefix sums -- integer, so any scan gives the same numbers) and
+ * consts_out[dim + 2] = bandwidth[0..dim), sum(log(bandwidth)) (:122), 0.5*dim*log(2 pi) (:121). */
+int glabc_kde_fit(const float* x, const float* w_raw, int64_t n_samples, int32_t dim, double h, const float* bw_fixed,
+                  float* weights_out, float* log_w_out, int64_t* wq_out, float* consts_out, void* stream);
+
+typedef struct glabc_kde {
+    int32_t dim;                   /* 1..GLABC_MAX_DIM */
+    int32_t reserved;
+    int64_t n_samples;
+    const float* x;                /* [dim][n_samples] kernel centres */
+    const float* log_w;            /* [n_samples] log(weights + 1e-10) */
+    const int64_t* cum_q;          /* [n_samples] inclusive prefix sums of wq (glabc_kde_sample only; else may be NULL) */
+    float bandwidth[GLABC_MAX_DIM];
+    float sum_log_bw;              /* consts_out[dim] */
+    float c_2pi;                   /* consts_out[dim + 1] */
+} glabc_kde;
+
+/* KernelDensity.log_prob, kernel_density.py:96-128: out[p] = logsumexp_s( ((-0.5 * sum_d ((pt_pd - x_sd)/bw_d)^2
+ * - c_2pi) - sum_log_bw) + log_w_s ), the inner float32 operations in the reference's order; the logsumexp is
+ * max + log(sum exp(. - max)) with the sum taken exactly in 2^-40 fixed point (order-independent, so the lanes of a
+ * wavefront can share one point).  pts is dimension-major [dim][n_points]. */
+int glabc_kde_log_prob(const glabc_kde* kde, const float* pts, int64_t n_points, float* out, void* stream);
+
+/* KernelDensity.sample, kernel_density.py:130-150: row r (global id row0 + r) picks centre j = first index with
+ * cum_q[j] > floor(u * cum_q[n-1]), u the float64 uniform of Philox(seed; id, 0, 0) words 0-1 (torch.multinomial
+ * with replacement is the same inverse-CDF draw on torch's generator), and adds bandwidth_d * normal_d (normals from
+ * words 2-3 of block 0, then blocks 1..).  out is dimension-major [dim][n]. */
+int glabc_kde_sample(const glabc_kde* kde, int64_t n, uint64_t seed, int64_t row0, float* out, void* stream);
+
+/* AGLMCMC.py:199-204 (and :104-109): weights of a proposal pool from its stored discrepancies,
+ * w[r] = exp((prior(theta_r) + calculate_log_kernel_dis(dis_r)) - log_q[r]), NaN -> 0.  The threshold is the one in
+ * model->kern_* (the caller passes a copy of its descriptor with the annealed eps_hat, Mixture.py:47-53).
+ * theta is dimension-major [theta_dim][n]. */
+int glabc_kde_train_weights(const glabc_model* model, const float* theta, const float* dis, const float* log_q, int64_t n,
+                            float* w_out, void* stream);
 
 /* Test hooks (not part of the sampling API): evaluate include/glabc_numerics.h on the device.
  * op 0 expf, 1 logf, 2 sin(2 pi u), 3 cos(2 pi u) on float bit patterns in[n] -> out[n];

@@ -29,6 +29,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../include/glabc.h"
@@ -184,6 +185,32 @@ ORACLE_API int oracle_dist_forward(const glabc_dist* dist, const float* noise, i
             log_p[i] = uniform_forward(dist, noise + i * dist->dim, z + i * dist->dim);
         else
             return GLABC_ERR_KIND;
+    }
+    return 0;
+}
+
+/* forward() with the device entry point's Philox draws (include/glabc.h, glabc_dist_forward); z is [dim][n]. */
+ORACLE_API int oracle_dist_forward_philox(const glabc_dist* dist, int64_t n, uint64_t seed, int64_t row0, float* z, float* log_p)
+{
+    if (!dist || !z || !log_p) return GLABC_ERR_NULL;
+    if (dist->dim < 1 || dist->dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    if (dist->kind != GLABC_DIST_DIAG_GAUSS && dist->kind != GLABC_DIST_UNIFORM) return GLABC_ERR_KIND;
+    int D = dist->dim;
+    for (int64_t r = 0; r < n; ++r) {
+        uint64_t gid = (uint64_t)(row0 + r);
+        float e[GLABC_MAX_DIM + 4], zz[GLABC_MAX_DIM];
+        for (int b = 0; b < (D + 3) / 4; ++b) {
+            glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, (uint32_t)b, (uint32_t)seed,
+                                                (uint32_t)(seed >> 32));
+            if (dist->kind == GLABC_DIST_UNIFORM) {
+                for (int q = 0; q < 4; ++q) e[4 * b + q] = glabc_uniform_f32(w.v[q]);
+            } else {
+                glabc_normal_pair(w.v[0], w.v[1], &e[4 * b], &e[4 * b + 1]);
+                glabc_normal_pair(w.v[2], w.v[3], &e[4 * b + 2], &e[4 * b + 3]);
+            }
+        }
+        log_p[r] = dist->kind == GLABC_DIST_UNIFORM ? uniform_forward(dist, e, zz) : diag_gauss_forward(dist, e, zz);
+        for (int j = 0; j < D; ++j) z[j * n + r] = zz[j];
     }
     return 0;
 }
@@ -1114,6 +1141,156 @@ ORACLE_API int oracle_pool_weights(const glabc_model* m, const float* theta, con
         float v = glabc_expf(lw);                                                           /* :82 */
         for (int j = 0; j < d; ++j) x_out[j * n + r] = y[j];
         w_out[r] = isnan(v) ? 0.0f : v;                                                     /* :83-85 */
+    }
+    return 0;
+}
+
+/* ---- KernelDensity (kernel_density.py:4-177) and AGLMCMC's pool weights (AGLMCMC.py:104-109,199-204) ---------- */
+
+/* float64 sum of 256 strided partials combined by a binary tree: the fixed order glabc_kde_fit documents */
+static double strided_tree_sum(const double* term, int64_t n)
+{
+    double part[256];
+    for (int t = 0; t < 256; ++t) {
+        double p = 0.0;
+        for (int64_t i = t; i < n; i += 256) p = p + term[i];
+        part[t] = p;
+    }
+    for (int s = 128; s >= 1; s >>= 1)
+        for (int t = 0; t < s; ++t) part[t] = part[t] + part[t + s];
+    return part[0];
+}
+
+ORACLE_API int oracle_kde_fit(const float* x, const float* w_raw, int64_t n, int32_t dim, double h, const float* bw_fixed,
+                              float* weights, float* log_w, int64_t* wq, float* consts)
+{
+    if (!x || !weights || !log_w || !wq || !consts) return GLABC_ERR_NULL;
+    if (dim < 1 || dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    if (n < 1) return GLABC_ERR_ARG;
+    double* term = (double*)malloc(sizeof(double) * (size_t)n);
+    float wsum32 = 0.0f;
+    if (w_raw) {
+        for (int64_t i = 0; i < n; ++i) term[i] = (double)w_raw[i];
+        wsum32 = (float)strided_tree_sum(term, n);
+    }
+    for (int64_t i = 0; i < n; ++i) {                                            /* kernel_density.py:83-87 */
+        float w = w_raw ? w_raw[i] / wsum32 : 1.0f / (float)n;
+        weights[i] = w;
+        log_w[i] = glabc_logf(w + 1e-10f);                                       /* :125 */
+        wq[i] = glabc_fx_quantize((double)w);
+    }
+    float bw[GLABC_MAX_DIM];
+    if (bw_fixed) {
+        for (int d = 0; d < dim; ++d) bw[d] = bw_fixed[d];
+    } else {                                                                     /* weighted_std, :40-68 */
+        float hf = (float)h;
+        for (int64_t i = 0; i < n; ++i) term[i] = (double)weights[i];
+        float w2 = (float)strided_tree_sum(term, n);                             /* :54 */
+        for (int64_t i = 0; i < n; ++i) {
+            float w = weights[i] / w2;
+            term[i] = (double)(w * w);
+        }
+        float corr = 1.0f - (float)strided_tree_sum(term, n);                    /* :64 */
+        corr = corr < 1e-10f ? 1e-10f : corr;                                    /* :65 */
+        for (int d = 0; d < dim; ++d) {
+            for (int64_t i = 0; i < n; ++i) term[i] = (double)((weights[i] / w2) * x[d * n + i]);
+            float mean = (float)strided_tree_sum(term, n);                       /* :57 */
+            for (int64_t i = 0; i < n; ++i) {
+                float diff = x[d * n + i] - mean;                                /* :60 */
+                term[i] = (double)((weights[i] / w2) * (diff * diff));
+            }
+            float var = (float)strided_tree_sum(term, n) / corr;                 /* :62-65 */
+            bw[d] = hf * sqrtf(var);                                             /* :67, :36 */
+        }
+    }
+    float lb[GLABC_MAX_DIM];
+    for (int d = 0; d < dim; ++d) {
+        consts[d] = bw[d];
+        lb[d] = glabc_logf(bw[d]);
+    }
+    consts[dim] = aten_rowsum_f32(lb, dim);                                      /* :122 */
+    consts[dim + 1] = (float)(0.5 * dim) * 1.8378770351409912f;                  /* :121, float32 log(2 pi) */
+    free(term);
+    return 0;
+}
+
+static float kde_log_term(const glabc_kde* k, const float* pt, int64_t s)
+{
+    float t[GLABC_MAX_DIM];
+    for (int d = 0; d < k->dim; ++d) {
+        float e = (pt[d] - k->x[d * k->n_samples + s]) / k->bandwidth[d];        /* :117 */
+        t[d] = e * e;
+    }
+    float lk = -0.5f * aten_rowsum_f32(t, k->dim);                               /* :118 */
+    lk = lk - k->c_2pi;                                                          /* :121 */
+    lk = lk - k->sum_log_bw;                                                     /* :122 */
+    return lk + k->log_w[s];                                                     /* :125 */
+}
+
+ORACLE_API int oracle_kde_log_prob(const glabc_kde* k, const float* pts, int64_t n_points, float* out)
+{
+    if (!k || !pts || !out) return GLABC_ERR_NULL;
+    for (int64_t p = 0; p < n_points; ++p) {
+        float pt[GLABC_MAX_DIM];
+        for (int d = 0; d < k->dim; ++d) pt[d] = pts[d * n_points + p];
+        float m = -INFINITY;
+        int nan = 0;
+        for (int64_t s = 0; s < k->n_samples; ++s) {                             /* torch.logsumexp: amax, :126 */
+            float lk = kde_log_term(k, pt, s);
+            nan |= isnan(lk);
+            m = lk > m ? lk : m;
+        }
+        float m0 = isinf(m) ? 0.0f : m;
+        if (nan) { out[p] = NAN; continue; }
+        if (m == INFINITY) { out[p] = m; continue; }
+        int64_t acc = 0;
+        for (int64_t s = 0; s < k->n_samples; ++s)
+            acc += glabc_fx_quantize((double)glabc_expf(kde_log_term(k, pt, s) - m0));
+        out[p] = glabc_logf((float)((double)acc * 0x1p-40)) + m0;
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_kde_sample(const glabc_kde* k, int64_t n, uint64_t seed, int64_t row0, float* out)
+{
+    if (!k || !out || !k->cum_q) return GLABC_ERR_NULL;
+    int D = k->dim;
+    int64_t S = k->n_samples;
+    for (int64_t r = 0; r < n; ++r) {
+        uint64_t gid = (uint64_t)(row0 + r);
+        float nrm[GLABC_MAX_DIM + 6];
+        double u = 0.0;
+        int nb = (D + 2 + 3) / 4;
+        for (int b = 0; b < nb; ++b) {
+            glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, (uint32_t)b, (uint32_t)seed,
+                                                (uint32_t)(seed >> 32));
+            if (b == 0) {
+                u = glabc_uniform_f64(w.v[0], w.v[1]);
+                glabc_normal_pair(w.v[2], w.v[3], &nrm[0], &nrm[1]);
+            } else {
+                glabc_normal_pair(w.v[0], w.v[1], &nrm[4 * b - 2], &nrm[4 * b - 1]);
+                glabc_normal_pair(w.v[2], w.v[3], &nrm[4 * b], &nrm[4 * b + 1]);
+            }
+        }
+        int64_t target = (int64_t)(u * (double)k->cum_q[S - 1]);
+        int64_t j = 0;
+        while (j < S - 1 && !(k->cum_q[j] > target)) ++j;                        /* torch.multinomial: inverse CDF, :141 */
+        for (int d = 0; d < D; ++d) out[d * n + r] = k->x[d * S + j] + nrm[d] * k->bandwidth[d];   /* :147-148 */
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_kde_train_weights(const glabc_model* m, const float* theta, const float* dis, const float* log_q, int64_t n,
+                                        float* w_out)
+{
+    int rc = model_check(m);
+    if (rc) return rc;
+    int d = m->theta_dim;
+    for (int64_t r = 0; r < n; ++r) {
+        float th[GLABC_MAX_DIM];
+        for (int j = 0; j < d; ++j) th[j] = theta[j * n + r];
+        float v = glabc_expf((model_prior(m, th) + model_log_kernel_dis(m, dis[r])) - log_q[r]);   /* AGLMCMC.py:200-201 */
+        w_out[r] = isnan(v) ? 0.0f : v;
     }
     return 0;
 }

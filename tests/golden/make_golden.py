@@ -494,8 +494,56 @@ def gradient_fixture():
     print("glmala_gradient: %d points" % n)
 
 
+def kde_fixture():
+    """KernelDensity.fit / log_prob (kernel_density.py:70-128) and AGLMCMC's training weights (AGLMCMC.py:199-201,
+    Mixture.py:47-53) evaluated by the reference on the CPU."""
+    import glabcmcmc.kernel_density as rkde
+    rng = np.random.default_rng(77)
+    out = {}
+    cases = [("a", 2, 400, True, "silverman"), ("b", 1, 64, False, "scott"), ("c", 3, 200, True, 0.3),
+             ("d", 4, 150, True, torch.tensor([0.2, 0.5, 0.1, 1.5])), ("e", 2, 3000, True, "silverman")]
+    for tag, d, n, weighted, bw in cases:
+        X = (rng.standard_normal((n, d)) * rng.uniform(0.3, 2.0, d) + rng.uniform(-1, 1, d)).astype(np.float32)
+        w = np.exp(rng.standard_normal(n) * 1.5).astype(np.float32) if weighted else None
+        if tag == "c":
+            w[:20] = 1e-30
+        pts = np.concatenate([X[:40] + 0.1 * rng.standard_normal((40, d)), 4 * rng.standard_normal((40, d)),
+                              60 * rng.standard_normal((16, d))]).astype(np.float32)
+        k = rkde.KernelDensity(bandwidth=bw, device="cpu")
+        k.fit(torch.from_numpy(X), None if w is None else torch.from_numpy(w))
+        lp = k.log_prob(torch.from_numpy(pts))
+        bw_out = k.bandwidth if isinstance(k.bandwidth, torch.Tensor) else torch.ones(d) * k.bandwidth
+        out.update({tag + "_X": X, tag + "_pts": pts, tag + "_bandwidth": bw_out.numpy().astype(np.float32),
+                    tag + "_weights": k.weights.numpy(), tag + "_log_prob": lp.numpy()})
+        if w is not None:
+            out[tag + "_w"] = w
+        if not isinstance(bw, str):
+            out[tag + "_bw_in"] = np.asarray(bw, np.float32).reshape(-1)
+    out["cases"] = np.array(repr([(t, d, n, wt, bw if isinstance(bw, str) else "fixed") for t, d, n, wt, bw in cases]))
+    # training weights under an annealed threshold
+    model = Mixture_set(0.05)
+    n = 512
+    theta = (rng.standard_normal((n, 2)) * 1.2).astype(np.float32)
+    dis = np.abs(rng.standard_normal(n) * 1.5).astype(np.float32)
+    logq = (rng.standard_normal(n) - 2).astype(np.float32)
+    for j, eps in enumerate([0.05, 0.7311, 2.5]):
+        lw = model.prior_log_prob(torch.from_numpy(theta)) + model.calculate_log_kernel_dis(torch.from_numpy(dis), eps) \
+            - torch.from_numpy(logq)
+        out["tw%d" % j] = torch.exp(lw).numpy()
+        ls = torch.log(torch.tensor([eps]))
+        out["tw%d_consts" % j] = np.array([eps, float(ls), float(torch.exp(ls))], np.float64)
+    out.update(tw_theta=theta, tw_dis=dis, tw_logq=logq)
+    cfg = dict(epsilon=0.05, local=G2(0.35), **{"global": G2(1.0)})
+    out.update(reference_constants(cfg))
+    out["cfg"] = np.array(repr(cfg))
+    np.savez_compressed(os.path.join(HERE, "kde.npz"), **out)
+    print("kde: %d arrays" % len(out))
+
+
 if __name__ == "__main__":
     want = sys.argv[1:]
+    if not want or "kde" in want:
+        kde_fixture()
     if not want or "primitives" in want:
         primitives()
     if not want or "glmala_gradient" in want:

@@ -85,7 +85,9 @@ def test_no_cpu_fallback():
         g.GLMALA(m, 10, torch.zeros(2), torch.zeros(1, 2), 0.3, 10, None, 0.5, dg, 5)
     with pytest.raises((RuntimeError, g._capi.HipLibraryMissing)):
         g.GLMCMC_NF(m, 10, torch.zeros(2), torch.zeros(1, 2), dg, None, 0.5, 10, 5, None, 1)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        g.KernelDensity().fit(torch.zeros(4, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         g.AGLMCMC(m, 10, torch.zeros(2), torch.zeros(1, 2), dg, dg, None, 0.5, 10, 5, 0.8, 0.2)
 
 
