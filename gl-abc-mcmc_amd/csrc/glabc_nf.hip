@@ -20,7 +20,8 @@
 // in registers (64-term fmaf chains) and exchange the two partial sums with one ds_swizzle.  f32-input MFMA is
 // exact float32 (bit-for-bit a k-ordered fmaf chain, MI355X_MICROARCH.md), so the CPU checker reproduces every
 // output bit.  Weights of the current coupling live in LDS (W2^T 64 KiB + 3 KiB of vectors); a workgroup of
-// 4 waves pushes ROWS_PER_WG rows through a coupling before the next coupling's weights are staged.
+// 8 waves -- two per SIMD, so one wave's LDS / VALU gaps are filled by the other's MFMAs (85 -> 100 TFLOP/s) -- pushes
+// its rows through a coupling before the next coupling's weights are staged.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -41,10 +42,12 @@ constexpr int NF_B3_OFF = NF_V4_OFF + 4 * NF_H;
 constexpr int NF_BLOCK_FLOATS = NF_B3_OFF + 4;                // = GLABC_NF_COUPLING_FLOATS
 static_assert(NF_BLOCK_FLOATS == GLABC_NF_COUPLING_FLOATS, "parameter block layout");
 
-constexpr int NF_WAVES = 4;
+#ifndef GLABC_NF_WAVES
+#define GLABC_NF_WAVES 8
+#endif
+constexpr int NF_WAVES = GLABC_NF_WAVES;                      // waves per workgroup (one workgroup per CU): 8 = two per SIMD
+constexpr int NF_MAX_PAIRS = 5;                               // 64-row pairs a wave keeps in registers, at most
 constexpr int NF_CUS = 256;
-// T = 32-row tiles a wave keeps in registers.  A launch is sized so that the grid is (a multiple of) the 256 CUs
-// and every workgroup stages each coupling's weights exactly once: rows per workgroup = 128 T.
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -58,65 +61,15 @@ struct NfArgs {
     float* log_q;                 // [n]
     int64_t n_rows, row0;
     uint32_t seed_lo, seed_hi;
+    int32_t rows_per_wg;          // multiple of 64
 };
 
-// (shift, log_s) of one coupling for this lane's row, conditioner input z0.  lds = staged parameter block.
-// k runs outermost: h1[k] is made on the fly (one fma + max) and feeds the four MFMAs of the four 32-neuron
-// output tiles, so the only live registers are the 4 x 16 accumulators.
-__device__ __forceinline__ void coupling_params(const float* __restrict__ lds, float z0, int lane, float& shift, float& log_s)
-{
-    const int half = lane >> 5, col = lane & 31;
-    // the accumulators start at the bias b2: the pre-activation of hidden unit i is the k-ascending fmaf chain
-    //   fma(W2[i][127], h1[127], ... fma(W2[i][0], h1[0], b2[i]))
-    f32x16 acc0, acc1, acc2, acc3;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        acc0[r] = lds[NF_V4_OFF + 4 * i];
-        acc1[r] = lds[NF_V4_OFF + 4 * (i + 32)];
-        acc2[r] = lds[NF_V4_OFF + 4 * (i + 64)];
-        acc3[r] = lds[NF_V4_OFF + 4 * (i + 96)];
-    }
-    const float* w1 = lds + NF_W1_OFF + half;
-    const float* b1 = lds + NF_B1_OFF + half;
-    const float* wt = lds + NF_W2_OFF + half * NF_H + col;                // W2^T[2s + half][32t + col]
-    // (explicit operand prefetch rings were tried and measured no better than the compiler's schedule: the loop is
-    // limited by MFMA / VALU issue interleave, not LDS latency -- tools/ubench/mfma_f32.hip)
-#pragma unroll 8
-    for (int s = 0; s < 64; ++s) {
-        const float h1 = __builtin_fmaxf(__builtin_fmaf(w1[2 * s], z0, b1[2 * s]), 0.0f);
-        const float* row = wt + 2 * s * NF_H;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[0], h1, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[32], h1, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[64], h1, acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[96], h1, acc3, 0, 0, 0);
-    }
-    float p0 = 0.0f, p1 = 0.0f;
-    auto epilogue = [&](const f32x16& acc, int t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float2 v = *reinterpret_cast<const float2*>(lds + NF_V4_OFF + 4 * i + 1);     // (W3[0][i], W3[1][i])
-            const float h2 = __builtin_fmaxf(acc[r], 0.0f);
-            p0 = __builtin_fmaf(v.x, h2, p0);
-            p1 = __builtin_fmaf(v.y, h2, p1);
-        }
-        __builtin_amdgcn_sched_barrier(0);        // keep the next tile's LDS reads from being hoisted above (VGPR pressure)
-    };
-    epilogue(acc0, 0);
-    epilogue(acc1, 1);
-    epilogue(acc2, 2);
-    epilogue(acc3, 3);
-    // partial sums of the two halves of the row: lane l <-> l + 32
-    const float q0 = __shfl_xor(p0, 32, 64), q1 = __shfl_xor(p1, 32, 64);
-    const float lo0 = half ? q0 : p0, hi0 = half ? p0 : q0;
-    const float lo1 = half ? q1 : p1, hi1 = half ? p1 : q1;
-    shift = (lo0 + hi0) + lds[NF_B3_OFF + 0];
-    log_s = (lo1 + hi1) + lds[NF_B3_OFF + 1];
-}
-
-// Two row tiles at once: every W2^T operand fetched from LDS feeds two MFMAs (rows of tile a and of tile b), which
-// halves the LDS reads and address arithmetic per MFMA.  Same arithmetic per row as coupling_params.
+// (shift, log_s) of one coupling for this lane's two rows (one in tile a, one in tile b), conditioner inputs z0a / z0b;
+// lds = the staged parameter block.  k runs outermost: h1[k] is made on the fly (one fma + max per tile) and every
+// W2^T operand fetched from LDS feeds two MFMAs (tile a and tile b), for each of the four 32-neuron output tiles.  The
+// accumulators start at the bias b2, so the pre-activation of hidden unit i is the k-ascending fmaf chain
+//   fma(W2[i][127], h1[127], ... fma(W2[i][0], h1[0], b2[i])).
+// (Explicit operand prefetch rings and other unroll factors were measured no better than the compiler's schedule.)
 __device__ __forceinline__ void coupling_params2(const float* __restrict__ lds, float z0a, float z0b, int lane, float& shift_a,
                                                  float& log_s_a, float& shift_b, float& log_s_b)
 {
@@ -176,22 +129,26 @@ __device__ __forceinline__ void coupling_params2(const float* __restrict__ lds, 
     log_s_b = ((half ? qb1 : pb1) + (half ? pb1 : qb1)) + b31;
 }
 
-template <bool INVERSE, int NF_TILES_PER_WAVE>
+template <bool INVERSE, int NP>
 __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
 {
-    constexpr int NF_ROWS_PER_WG = 32 * NF_WAVES * NF_TILES_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31;
-    const int64_t wg_row0 = (int64_t)blockIdx.x * NF_ROWS_PER_WG;
+    const int n_pairs = a.rows_per_wg / 64;                            // 64-row pairs of 32-row tiles in this workgroup
+    const int64_t wg_row0 = (int64_t)blockIdx.x * a.rows_per_wg;
 
-    // this lane's rows: tile q of the wave -> row wg_row0 + (wave*TILES + q)*32 + col
-    float z0[NF_TILES_PER_WAVE], z1[NF_TILES_PER_WAVE], lq[NF_TILES_PER_WAVE];
-    bool valid[NF_TILES_PER_WAVE];
+    // Pair p of the workgroup (rows wg_row0 + 64p .. +63) belongs to wave p % NF_WAVES, slot p / NF_WAVES: when the
+    // pairs do not divide evenly the extra ones land on waves 0.., i.e. on different SIMDs.  Tile 2q is the first
+    // 32 rows of the wave's q-th pair, tile 2q+1 the second.
+    float z0[2 * NP], z1[2 * NP], lq[2 * NP];
+    bool valid[2 * NP], active[NP];
 #pragma unroll
-    for (int q = 0; q < NF_TILES_PER_WAVE; ++q) {
-        const int64_t row = wg_row0 + (int64_t)(wave * NF_TILES_PER_WAVE + q) * 32 + col;
-        valid[q] = row < a.n_rows;
+    for (int q = 0; q < 2 * NP; ++q) {
+        const int pair = wave + (q >> 1) * NF_WAVES;
+        active[q >> 1] = pair < n_pairs;                               // wave-uniform
+        const int64_t row = wg_row0 + (int64_t)pair * 64 + (q & 1) * 32 + col;
+        valid[q] = active[q >> 1] && row < a.n_rows;
         const int64_t rr = valid[q] ? row : a.n_rows - 1;
         if (INVERSE) {
             z0[q] = a.in[rr];
@@ -237,7 +194,8 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
         };
         // inverse: flows reversed -> Permute^-1 (the swap again) first, so the conditioner input is z1
 #pragma unroll
-        for (int q = 0; q + 1 < NF_TILES_PER_WAVE; q += 2) {
+        for (int q = 0; q < 2 * NP; q += 2) {
+            if (!active[q >> 1]) continue;
             const float ca = INVERSE ? z1[q] : z0[q], cb = INVERSE ? z1[q + 1] : z0[q + 1];
             const float ta = z0[q], tb = z0[q + 1];
             float sa, la, sb, lb;
@@ -245,18 +203,12 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
             apply(q, sa, la, ca, ta);
             apply(q + 1, sb, lb, cb, tb);
         }
-        if constexpr (NF_TILES_PER_WAVE % 2 == 1) {
-            constexpr int q = NF_TILES_PER_WAVE - 1;
-            const float ca = INVERSE ? z1[q] : z0[q], ta = z0[q];
-            float sa, la;
-            coupling_params(lds, ca, lane, sa, la);
-            apply(q, sa, la, ca, ta);
-        }
     }
 
 #pragma unroll
-    for (int q = 0; q < NF_TILES_PER_WAVE; ++q) {
-        const int64_t row = wg_row0 + (int64_t)(wave * NF_TILES_PER_WAVE + q) * 32 + col;
+    for (int q = 0; q < 2 * NP; ++q) {
+        const int pair = wave + (q >> 1) * NF_WAVES;
+        const int64_t row = wg_row0 + (int64_t)pair * 64 + (q & 1) * 32 + col;
         if (valid[q] && lane < 32) {
             if (INVERSE) {
                 // + q0.log_prob(z): C - sum(log_scale + 0.5 ((z - loc)/exp(log_scale))^2)
@@ -309,36 +261,43 @@ static NfArgs nf_pack(const glabc_flow* f, const float* in, float* z, float* log
     return a;
 }
 
-template <bool INV, int T>
-static int nf_launch_t(const NfArgs& a, hipStream_t s)
+template <bool INV, int NP>
+static int nf_launch_np(NfArgs a, int rows_per_wg, hipStream_t s)
 {
     const size_t lds_bytes = sizeof(float) * NF_BLOCK_FLOATS;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)nf_kernel<INV, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)nf_kernel<INV, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return GLABC_ERR_LAUNCH;
         attr_set = true;
     }
-    const int64_t rows_per_wg = 32 * NF_WAVES * T;
+    a.rows_per_wg = rows_per_wg;
     const unsigned grid = (unsigned)((a.n_rows + rows_per_wg - 1) / rows_per_wg);
-    hipLaunchKernelGGL((nf_kernel<INV, T>), dim3(grid), dim3(64 * NF_WAVES), lds_bytes, s, a);
+    hipLaunchKernelGGL((nf_kernel<INV, NP>), dim3(grid), dim3(64 * NF_WAVES), lds_bytes, s, a);
     return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
 }
 
-// tiles per wave: the smallest compiled T whose 256-workgroup grid (one workgroup per CU) covers the rows,
-// so that the chip is filled evenly and each workgroup stages every coupling once
+// Rows per workgroup: the rows are spread over (a multiple of) the 256 CUs in 64-row pairs, one workgroup per CU,
+// so the chip is filled evenly and each workgroup stages every coupling once; a wave holds at most NF_MAX_PAIRS pairs.
 template <bool INV>
 static int nf_launch(const NfArgs& a, hipStream_t s)
 {
-    const int64_t per_t = (int64_t)NF_CUS * NF_WAVES * 32;            // rows covered per unit of T (one workgroup per CU)
-    const int64_t need = (a.n_rows + per_t - 1) / per_t;
-    // even T keeps every MFMA in the two-tiles-per-operand form; small inputs on half the grid (one workgroup per CU)
-    if (need <= 1) return nf_launch_t<INV, 1>(a, s);
-    if (need <= 2) return nf_launch_t<INV, 2>(a, s);
-    if (need <= 4) return nf_launch_t<INV, 4>(a, s);
-    if (need <= 6) return nf_launch_t<INV, 6>(a, s);
-    if (need <= 8) return nf_launch_t<INV, 8>(a, s);
-    return nf_launch_t<INV, 10>(a, s);                                // 327 680 rows = 256 workgroups x 1280; larger: more workgroups
+    const int64_t pairs = (a.n_rows + 63) / 64;
+    int64_t pairs_per_wg = (pairs + NF_CUS - 1) / NF_CUS;
+    const int64_t cap = (int64_t)NF_WAVES * NF_MAX_PAIRS;
+    if (pairs_per_wg > cap) {                                         // several rounds of workgroups per CU
+        const int64_t rounds = (pairs_per_wg + cap - 1) / cap;
+        pairs_per_wg = (pairs + NF_CUS * rounds - 1) / (NF_CUS * rounds);
+    }
+    const int np = (int)((pairs_per_wg + NF_WAVES - 1) / NF_WAVES);
+    const int rows_per_wg = (int)pairs_per_wg * 64;
+    switch (np) {
+    case 1: return nf_launch_np<INV, 1>(a, rows_per_wg, s);
+    case 2: return nf_launch_np<INV, 2>(a, rows_per_wg, s);
+    case 3: return nf_launch_np<INV, 3>(a, rows_per_wg, s);
+    case 4: return nf_launch_np<INV, 4>(a, rows_per_wg, s);
+    default: return nf_launch_np<INV, NF_MAX_PAIRS>(a, rows_per_wg, s);
+    }
 }
 
 extern "C" {
