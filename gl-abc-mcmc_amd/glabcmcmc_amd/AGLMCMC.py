@@ -76,6 +76,9 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
     num_train, eps_num = 0, 0
     hat_eps = 1000000.0                                                                           # :119
     log_q_old = torch.empty(n, dtype=torch.float32, device=dev)
+    # a chain uses at most one pool slice per iteration: the device is only asked (a sync) whether a pool is used up
+    # when that has become possible -- the same schedule as checking after every iteration
+    countdown = int(step_size)
     for i in range(1, num_ite):
         with torch.cuda.device(dev):
             if KDE is None:                                                                       # :137-140
@@ -93,8 +96,14 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
             run.history, run.hist_stride = hist[i].data_ptr(), n
             _capi.check(lib.glabc_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pd), C.byref(cs), C.byref(run),
                                                  stream), "glabc_glmcmc_nf_step")                 # :125-172, 251-272
-        if int(kk.max().item()) < int(step_size):                                                 # :175
+        countdown -= 1
+        if countdown > 0:
             continue
+        used = int(kk.max().item())
+        if used < int(step_size):                                                                 # :175
+            countdown = int(step_size) - used
+            continue
+        countdown = int(step_size)
         dis0 = pool["dis"]
         if hat_eps > hat_eps_T:                                                                   # :179-196
             eps_num += 1
@@ -102,6 +111,8 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
             valid = dis0[~torch.isnan(dis0)]
             if valid.numel() > 0:
                 q = torch.clamp((alpha * num_a / valid.shape[0]).to(dis0.dtype), 0.0, 1.0)
+                if valid.numel() > (1 << 24):                                                     # torch.quantile's input limit
+                    valid = valid[:: (valid.numel() >> 24) + 1]
                 hat_eps = float(torch.quantile(valid, q))
             hat_eps = max(hat_eps, float(hat_eps_T))
         train_model = ABCset.descriptor(hat_eps)                                                  # calculate_log_kernel_dis(dis0, hat_eps), :199

@@ -71,9 +71,12 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     refresh, num_train = 0, 0
     draw_pool(refresh)
     log_q_old = torch.empty(n, dtype=torch.float32, device=dev)
+    blob = flow.packed_params()                                                                    # repacked only after an optimizer step
+    fdesc = flow.descriptor(blob)
+    # a chain uses at most one pool slice per iteration, so the pools cannot run out before `countdown` more
+    # iterations: the device is only asked (a sync) when that is possible -- same schedule as checking every iteration
+    countdown = int(step_size)
     for i in range(1, num_ite):
-        blob = flow.packed_params()
-        fdesc = flow.descriptor(blob)
         with torch.cuda.device(dev):
             _capi.check(lib.glabc_nf_log_prob(C.byref(fdesc), chains.theta.data_ptr(), n, log_q_old.data_ptr(), stream),
                         "glabc_nf_log_prob")                                                       # :96-98
@@ -86,22 +89,31 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
             run.history, run.hist_stride = hist[i].data_ptr(), n
             _capi.check(lib.glabc_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pd), C.byref(cs), C.byref(run),
                                                  stream), "glabc_glmcmc_nf_step")
-        if int(kk.max().item()) >= int(step_size):                                                 # :112
-            if num_train < Train_step:                                                             # :114-124
-                flow.train()
-                optimizer.zero_grad()
-                w = pool["w"]
-                Train_weight = w / torch.sum(w)
-                idx = resample(Train_weight, w.numel())
-                Train_t = pool["theta"].t()[idx].detach().float()
-                loss = flow.forward_kld(Train_t)
-                if not (torch.isnan(loss) | torch.isinf(loss)):
-                    loss.backward()
-                optimizer.step()                                                                   # (B11: steps even when backward was skipped)
-                num_train += 1
-                losses.append(float(loss.detach()))
-            refresh += 1
-            draw_pool(refresh)                                                                     # :125-140
+        countdown -= 1
+        if countdown > 0:
+            continue
+        used = int(kk.max().item())
+        if used < int(step_size):                                                                  # :112
+            countdown = int(step_size) - used
+            continue
+        if num_train < Train_step:                                                                 # :114-124
+            flow.train()
+            optimizer.zero_grad()
+            w = pool["w"]
+            Train_weight = w / torch.sum(w)
+            idx = resample(Train_weight, w.numel())
+            Train_t = pool["theta"].t()[idx].detach().float()
+            loss = flow.forward_kld(Train_t)
+            if not (torch.isnan(loss) | torch.isinf(loss)):
+                loss.backward()
+            optimizer.step()                                                                       # (B11: steps even when backward was skipped)
+            num_train += 1
+            losses.append(float(loss.detach()))
+            blob = flow.packed_params()
+            fdesc = flow.descriptor(blob)
+        refresh += 1
+        draw_pool(refresh)                                                                         # :125-140
+        countdown = int(step_size)
     if state_out is not None:
         state_out.update(chains=chains, flow=flow, loss_hist=losses, num_train=num_train)
     return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)
