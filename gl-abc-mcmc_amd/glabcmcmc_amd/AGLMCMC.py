@@ -79,6 +79,10 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
     # a chain uses at most one pool slice per iteration: the device is only asked (a sync) whether a pool is used up
     # when that has become possible -- the same schedule as checking after every iteration
     countdown = int(step_size)
+    cs = chains.struct()                                                                          # the state arrays never move
+    run = _capi.Run()
+    run.seed, run.n_steps, run.global_frequency, run.batch_size, run.hist_stride = key, 1, float(global_frequency), N, n
+    hist_ptr, hist_row_bytes = hist.data_ptr(), hist[0].numel() * 4
     for i in range(1, num_ite):
         with torch.cuda.device(dev):
             if KDE is None:                                                                       # :137-140
@@ -89,11 +93,7 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
                 log_q_old = KDE.log_prob_soa(chains.theta)
             pd = _capi.Pool(pool["theta"].data_ptr(), pool["x"].data_ptr(), pool["w"].data_ptr(), log_q_old.data_ptr(),
                             kk.data_ptr(), int(step_size), 0)
-            cs = chains.struct()
-            run = _capi.Run()
-            run.seed, run.step0, run.n_steps = key, i, 1
-            run.global_frequency, run.batch_size = float(global_frequency), N
-            run.history, run.hist_stride = hist[i].data_ptr(), n
+            run.step0, run.history = i, hist_ptr + i * hist_row_bytes
             _capi.check(lib.glabc_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pd), C.byref(cs), C.byref(run),
                                                  stream), "glabc_glmcmc_nf_step")                 # :125-172, 251-272
         countdown -= 1

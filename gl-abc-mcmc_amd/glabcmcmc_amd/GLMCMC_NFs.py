@@ -76,17 +76,17 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     # a chain uses at most one pool slice per iteration, so the pools cannot run out before `countdown` more
     # iterations: the device is only asked (a sync) when that is possible -- same schedule as checking every iteration
     countdown = int(step_size)
+    cs = chains.struct()                                                                          # the state arrays never move
+    run = _capi.Run()
+    run.seed, run.n_steps, run.global_frequency, run.batch_size, run.hist_stride = key, 1, float(global_frequency), N, n
+    hist_ptr, hist_row_bytes = hist.data_ptr(), hist[0].numel() * 4
     for i in range(1, num_ite):
         with torch.cuda.device(dev):
             _capi.check(lib.glabc_nf_log_prob(C.byref(fdesc), chains.theta.data_ptr(), n, log_q_old.data_ptr(), stream),
                         "glabc_nf_log_prob")                                                       # :96-98
             pd = _capi.Pool(pool["theta"].data_ptr(), pool["x"].data_ptr(), pool["w"].data_ptr(), log_q_old.data_ptr(),
                             kk.data_ptr(), int(step_size), 0)
-            cs = chains.struct()
-            run = _capi.Run()
-            run.seed, run.step0, run.n_steps = key, i, 1
-            run.global_frequency, run.batch_size = float(global_frequency), N
-            run.history, run.hist_stride = hist[i].data_ptr(), n
+            run.step0, run.history = i, hist_ptr + i * hist_row_bytes
             _capi.check(lib.glabc_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pd), C.byref(cs), C.byref(run),
                                                  stream), "glabc_glmcmc_nf_step")
         countdown -= 1

@@ -28,6 +28,7 @@ class KernelDensity:
         self._fitted = False
         self._seed = seed
         self._rows_drawn = 0
+        self._desc = None
 
     def _rule_factor(self, n):
         """kernel_density.py:24-33 (Python floats)"""
@@ -73,18 +74,22 @@ class KernelDensity:
         self._consts = [float(v) for v in c]
         self.bandwidth = c[:d].to(dev)                                         # kernel_density.py:90-92
         self._fitted = True
+        self._desc = None
         return self
 
     def descriptor(self):
         """glabc_kde (include/glabc.h)"""
         if not self._fitted:
             raise RuntimeError("Must call fit() before computing probabilities")
+        if self._desc is not None:
+            return self._desc
         k = _capi.Kde()
         k.dim, k.n_samples = self.dim, self.n_samples
         k.x, k.log_w, k.cum_q = self._x.data_ptr(), self._log_w.data_ptr(), self._cum_q.data_ptr()
         for j in range(self.dim):
             k.bandwidth[j] = self._consts[j]
         k.sum_log_bw, k.c_2pi = self._consts[self.dim], self._consts[self.dim + 1]
+        self._desc = k
         return k
 
     def log_prob_soa(self, pts):
