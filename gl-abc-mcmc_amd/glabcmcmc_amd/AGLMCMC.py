@@ -30,6 +30,8 @@ from . import _capi, _host, engine
 from .kernel_density import KernelDensity
 
 _LOG_PRIOR_FLOOR = float(np.log(10 ** (-10)))                                       # AGLMCMC.py:224
+# Philox keys of the three pool-side streams (key ^ constant); the per-iteration draws use the run key itself
+ISIR_STREAM, POOL_STREAM, KDE_STREAM = 0x9E3779B97F4A7C15, 0x5851F42D4C957F2D, 0xD1B54A32D192ED03
 
 
 def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_ISIR_prop,
@@ -56,7 +58,7 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
         dis = torch.empty(rows, dtype=torch.float32, device=dev)
         x_rows = None
         with torch.cuda.device(dev):
-            _capi.check(lib.glabc_pool_weights(C.byref(model), theta.data_ptr(), lq.data_ptr(), rows, key ^ 0x5851F42D4C957F2D,
+            _capi.check(lib.glabc_pool_weights(C.byref(model), theta.data_ptr(), lq.data_ptr(), rows, key ^ POOL_STREAM,
                                                refresh[0] * rows, x.data_ptr(), w.data_ptr(), stream), "glabc_pool_weights")
             x_rows = x.t().contiguous()
             _capi.check(lib.glabc_model_discrepancy(C.byref(model), x_rows.data_ptr(), rows, dis.data_ptr(), stream),
@@ -68,11 +70,12 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
     theta0 = torch.empty(d, rows, dtype=torch.float32, device=dev)
     lq0 = torch.empty(rows, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _capi.check(lib.glabc_dist_forward(C.byref(isir), rows, key ^ 0x9E3779B97F4A7C15, 0, theta0.data_ptr(), lq0.data_ptr(),
+        _capi.check(lib.glabc_dist_forward(C.byref(isir), rows, key ^ ISIR_STREAM, 0, theta0.data_ptr(), lq0.data_ptr(),
                                            stream), "glabc_dist_forward")                        # :80-81
     weigh_pool(theta0, lq0)
 
     KDE = None
+    kde_rows = [0]
     num_train, eps_num = 0, 0
     hat_eps = 1000000.0                                                                           # :119
     log_q_old = torch.empty(n, dtype=torch.float32, device=dev)
@@ -123,20 +126,21 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
         m = min(rows, int(max_train))
         keep = tw[:m] > 0                                                                         # :207-208
         if bool(keep.any()):
-            KDE = KernelDensity(bandwidth='silverman', device=dev, seed=key ^ 0xD1B54A32D192ED03)
+            KDE = KernelDensity(bandwidth='silverman', device=dev, seed=key ^ KDE_STREAM)
             KDE.fit(pool["theta"][:, :m].t()[keep], tw[:m][keep])                                 # :211-215
             num_train += 1
         if KDE is None:                                                                           # no usable weights yet: keep the ISIR proposal
             theta_new = torch.empty(d, rows, dtype=torch.float32, device=dev)
             lq_new = torch.empty(rows, dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
-                _capi.check(lib.glabc_dist_forward(C.byref(isir), rows, key ^ 0x9E3779B97F4A7C15, refresh[0] * rows,
+                _capi.check(lib.glabc_dist_forward(C.byref(isir), rows, key ^ ISIR_STREAM, refresh[0] * rows,
                                                    theta_new.data_ptr(), lq_new.data_ptr(), stream), "glabc_dist_forward")
             weigh_pool(theta_new, lq_new)
             continue
         got, parts = 0, []
         while got < rows:                                                                         # :220-226 (4x oversampling, prior floor)
-            cand = KDE.sample_soa(4 * rows)
+            cand = KDE.sample_soa(4 * rows, row0=kde_rows[0])                                     # one stream across all refits
+            kde_rows[0] += 4 * rows
             ok = ABCset.prior_log_prob(cand.t().contiguous()) > _LOG_PRIOR_FLOOR
             sel = cand[:, ok]
             parts.append(sel)

@@ -1280,6 +1280,28 @@ ORACLE_API int oracle_kde_sample(const glabc_kde* k, int64_t n, uint64_t seed, i
     return 0;
 }
 
+/* the raw draws of oracle_kde_sample (test hook for replaying the reference's AGLMCMC): u[n] float64, nrm[n][dim] */
+ORACLE_API void oracle_kde_draws(uint64_t seed, int64_t row0, int64_t n, int dim, double* u, float* nrm_out)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        uint64_t gid = (uint64_t)(row0 + r);
+        float nrm[GLABC_MAX_DIM + 6];
+        int nb = (dim + 2 + 3) / 4;
+        for (int b = 0; b < nb; ++b) {
+            glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, (uint32_t)b, (uint32_t)seed,
+                                                (uint32_t)(seed >> 32));
+            if (b == 0) {
+                u[r] = glabc_uniform_f64(w.v[0], w.v[1]);
+                glabc_normal_pair(w.v[2], w.v[3], &nrm[0], &nrm[1]);
+            } else {
+                glabc_normal_pair(w.v[0], w.v[1], &nrm[4 * b - 2], &nrm[4 * b - 1]);
+                glabc_normal_pair(w.v[2], w.v[3], &nrm[4 * b], &nrm[4 * b + 1]);
+            }
+        }
+        for (int d = 0; d < dim; ++d) nrm_out[r * dim + d] = nrm[d];
+    }
+}
+
 ORACLE_API int oracle_kde_train_weights(const glabc_model* m, const float* theta, const float* dis, const float* log_q, int64_t n,
                                         float* w_out)
 {

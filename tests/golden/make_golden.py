@@ -494,6 +494,98 @@ def gradient_fixture():
     print("glmala_gradient: %d points" % n)
 
 
+class AGTape(Tape):
+    """Tape for the reference's AGLMCMC (AGLMCMC.py:44-289): the per-iteration draws of the base tape (branch / accept
+    uniforms, resampling double, the local move's 2 x (1, d) normals) plus the pool-side draws of the build's AGLMCMC
+    (glabcmcmc_amd/AGLMCMC.py): the initial ISIR pool, the simulator noise of each pool, and for every KDE refit the
+    4P centre-index uniforms + kernel noise.  torch.multinomial is replaced by the inverse-CDF rule of glabc_kde_sample
+    (integer weights rint(w 2^40), first index whose inclusive prefix sum exceeds floor(u total))."""
+
+    def __init__(self, L, key, T, P, d, gf):
+        from glabcmcmc_amd.AGLMCMC import ISIR_STREAM, KDE_STREAM, POOL_STREAM
+        u, r, z = philox_tape(L, key, 0, T, 1, d, d, False, False, gf)
+        super().__init__(u, r, z, d, gf, True)
+        self.L, self.key, self.P = L, key, P
+        self.streams = (key ^ ISIR_STREAM, key ^ POOL_STREAM, key ^ KDE_STREAM)
+        self.pools_drawn = 0          # simulator-noise blocks handed out
+        self.init_done = False
+        self.kde_calls = 0
+        self.kde_u = None
+
+    def _row_normals(self, seed, row0, n):
+        unit = rdist.DiagGaussian(self.d, torch.zeros(self.d), torch.zeros(self.d))
+        from glabcmcmc_amd import distribution as bdist
+        desc = bdist.DiagGaussian(self.d, torch.zeros(self.d), torch.zeros(self.d)).descriptor()
+        z = np.zeros((self.d, n), np.float32)
+        lp = np.zeros(n, np.float32)
+        import ctypes
+        assert self.L.oracle_dist_forward_philox(ctypes.byref(desc), n, seed, row0, z.ctypes.data, lp.ctypes.data) == 0
+        return torch.from_numpy(np.ascontiguousarray(z.T))
+
+    def randn(self, *size, **kw):
+        if len(size) == 1 and isinstance(size[0], (tuple, list)):
+            size = tuple(size[0])
+        n = size[0]
+        if n == self.P:
+            if not self.init_done:                                         # ISIR_prop.forward(P), AGLMCMC.py:80
+                self.init_done = True
+                return self._row_normals(self.streams[0], 0, n)
+            k = self.pools_drawn                                           # generate_samples(Theta_prop0), :90 / :232
+            self.pools_drawn += 1
+            return self._row_normals(self.streams[1], k * self.P, n)
+        if n == 4 * self.P:                                                # KDE.sample noise, kernel_density.py:147
+            nrm = np.zeros((n, self.d), np.float32)
+            uu = np.zeros(n, np.float64)
+            self.L.oracle_kde_draws(self.streams[2], (self.kde_calls - 1) * n, n, self.d, uu.ctypes.data, nrm.ctypes.data)
+            return torch.from_numpy(nrm)
+        return self._noise(size)
+
+    def multinomial(self, weights, n, replacement=True):
+        assert replacement and n == 4 * self.P
+        nrm = np.zeros((n, self.d), np.float32)
+        uu = np.zeros(n, np.float64)
+        self.L.oracle_kde_draws(self.streams[2], self.kde_calls * n, n, self.d, uu.ctypes.data, nrm.ctypes.data)
+        self.kde_calls += 1
+        wq = np.rint(weights.detach().numpy().astype(np.float64) * 2.0 ** 40).astype(np.int64)
+        cum = np.cumsum(wq)
+        target = np.floor(uu * float(cum[-1])).astype(np.int64)
+        idx = np.minimum(np.searchsorted(cum, target, side="right"), len(cum) - 1)
+        return torch.from_numpy(idx)
+
+
+def aglmcmc_fixture():
+    """The reference's AGLMCMC, unmodified, on the AGTape: its chain comes back through the CSV it writes (the function
+    itself returns None, AGLMCMC.py:283-288)."""
+    import csv
+    import tempfile
+    import glabcmcmc.AGLMCMC as raglmcmc
+    L = oracle_lib.load()
+    cfgs = {"aglmcmc_philox": dict(epsilon=0.3, seed=3, T=1500, gf=0.6, step_size=40, batch_size=5, alpha=0.8, hat_eps_T=0.5,
+                                   local=G2(0.35), **{"global": ("gauss", [0.0, 0.0], [1.6487212, 1.6487212])})}
+    for name, cfg in cfgs.items():
+        T, P = cfg["T"], cfg["step_size"] * cfg["batch_size"]
+        tape = AGTape(L, cfg["seed"], T, P, 2, cfg["gf"])
+        model = Mixture_set(cfg["epsilon"])
+        local = make_dist(cfg["local"])
+        isir = rdist.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.5, 0.5]))
+        theta0 = torch.tensor([1.5, 1.5])
+        y0 = torch.tensor([[1.4, 1.7]])
+        saved = torch.multinomial
+        torch.multinomial = tape.multinomial
+        out = os.path.join(tempfile.mkdtemp(), "chain.csv")
+        try:
+            with patched(tape):
+                raglmcmc.AGLMCMC(model, T, theta0, y0, local, isir, out, cfg["gf"], cfg["step_size"], cfg["batch_size"],
+                                 cfg["alpha"], cfg["hat_eps_T"], device="cpu")
+        finally:
+            torch.multinomial = saved
+        rows = np.array([[np.float32(v) for v in row] for row in csv.reader(open(out))], np.float32)
+        assert rows.shape == (T, 2), rows.shape
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), chain=rows, theta0=theta0.numpy(), y0=y0.numpy(),
+                            kde_refits=np.array(tape.kde_calls), cfg=np.array(repr(cfg)), **reference_constants(cfg))
+        print("%s: %d rows, %d KDE refits, %d iterations consumed" % (name, len(rows), tape.kde_calls, tape.t + 1))
+
+
 def kde_fixture():
     """KernelDensity.fit / log_prob (kernel_density.py:70-128) and AGLMCMC's training weights (AGLMCMC.py:199-201,
     Mixture.py:47-53) evaluated by the reference on the CPU."""
@@ -544,6 +636,8 @@ if __name__ == "__main__":
     want = sys.argv[1:]
     if not want or "kde" in want:
         kde_fixture()
+    if not want or "aglmcmc" in want:
+        aglmcmc_fixture()
     if not want or "primitives" in want:
         primitives()
     if not want or "glmala_gradient" in want:

@@ -45,6 +45,7 @@ _SIG = {
                                  C.c_void_p, C.c_void_p]),
     "oracle_kde_log_prob": (C.c_int, [_P(A.Kde), C.c_void_p, C.c_int64, C.c_void_p]),
     "oracle_kde_sample": (C.c_int, [_P(A.Kde), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p]),
+    "oracle_kde_draws": (None, [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "oracle_kde_train_weights": (C.c_int, [_P(A.Model), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "oracle_dist_forward_philox": (C.c_int, [_P(A.Dist), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
     "oracle_gamma_log_prob": (C.c_int, [_P(A.GammaDesc), C.c_void_p, C.c_int64, C.c_void_p]),

@@ -271,3 +271,30 @@ def test_aglmcmc_end_to_end(hip, tmp_path):
     assert torch.allclose(pa.mean(0), pb.mean(0), atol=0.03), (pa.mean(0), pb.mean(0))
     assert torch.allclose(pa.std(0), pb.std(0), atol=0.03), (pa.std(0), pb.std(0))
     assert st["num_train"] >= 3
+
+
+@pytest.mark.gpu
+def test_aglmcmc_follows_the_reference_chain(hip):
+    """tests/golden/aglmcmc_philox.npz: the reference's AGLMCMC (unmodified loop, 1500 iterations, 22 KDE refits) driven by
+    the build's Philox streams (make_golden.AGTape).  The GPU sampler must walk the same chain.  Not bit for bit: after
+    the first refit the pool entries carry the KDE bandwidth, whose float32 sums the reference takes in torch's order
+    (1e-7 relative), so states agree to ~1e-6 -- and every accept / resample / centre-index decision must agree."""
+    from glabcmcmc_amd import AGLMCMC, distribution
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    g = load_golden("aglmcmc_philox")
+    cfg = eval(str(g["cfg"]))
+    Model = Mixture_set(cfg["epsilon"])
+    lp = distribution.DiagGaussian(2, loc=torch.zeros(2), log_scale=torch.log(torch.tensor([0.35, 0.35])))
+    ip = distribution.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.5, 0.5]))
+    st = {}
+    out = AGLMCMC(Model, cfg["T"], torch.from_numpy(g["theta0"]), torch.from_numpy(g["y0"]), lp, ip, None, cfg["gf"],
+                  cfg["step_size"], cfg["batch_size"], cfg["alpha"], cfg["hat_eps_T"], seed=cfg["seed"], verbose=False,
+                  state_out=st)
+    ref = g["chain"]
+    got = out.numpy()
+    assert got.shape == ref.shape
+    diff = np.abs(got - ref).max(1)
+    first_bad = int(np.argmax(diff > 1e-4)) if (diff > 1e-4).any() else -1
+    assert first_bad == -1, "chains part at iteration %d: %s vs %s" % (first_bad, got[first_bad], ref[first_bad])
+    assert st["num_train"] == int(g["kde_refits"])
+    assert np.array_equal(bits(got[:40]), bits(ref[:40]))                  # before the first refit: bit for bit
