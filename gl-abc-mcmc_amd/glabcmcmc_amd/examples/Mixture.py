@@ -87,3 +87,38 @@ class Mixture_set:
         m.kern_log_scale, m.kern_scale, m.kern_c0 = kern.p1[0], kern.p2[0], kern.c0
         m.epsilon = float(np.float32(epsilon))
         return m
+
+
+def main(num_ite=1000, output_dir='./', verbose=True):
+    """The reference's example script (examples/Mixture.py:55-85), every sampler enabled -- the reference keeps all but
+    run_glmcmc commented out.  Returns the five chains."""
+    from ..MCMCRunner import MCMCRunner
+    from ..ESJD import esjd
+    from ..flows import BaseDiagGaussian
+    Model = Mixture_set(epsilon=0.05)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    theta0 = torch.tensor([0.0, 0.0])
+    y0 = Model.generate_samples(theta0)
+    lp = distribution.DiagGaussian(2, loc=torch.zeros(1, 2), log_scale=torch.log(torch.tensor([0.35, 0.35])))
+    ip = distribution.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0]))
+    gp = distribution.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0]))
+    gp_base = BaseDiagGaussian(2)                                   # nf.distributions.base.DiagGaussian(2), Mixture.py:71
+    runner = MCMCRunner(Model, output_dir=output_dir)
+    kw = dict(verbose=verbose)
+    chains = {
+        "global": runner.run_global_mcmc(num_ite, theta0, y0, 0.5, lp, gp, output_file='global_mcmc_results.csv', **kw),
+        "glmcmc": runner.run_glmcmc(num_ite, theta0, y0, 0.9, lp, ip, 5, output_file='glmcmc_results.csv', **kw),
+        "aglmcmc": runner.run_aglmcmc(num_ite, theta0, y0, 1, lp, ip, 5, 200, 0.8, 0.2, output_file='aglmcmc_results.csv', **kw),
+        "glmala": runner.run_glmala(num_ite, theta0, y0, 0.8, ip, 5, 0.3, 100, output_file='glmala_results.csv', **kw),
+        "glmcmc_nf": runner.run_glmcmc_nf(num_ite, theta0, y0, 0.5, lp, gp_base, 5, 200, 50,
+                                          output_file='glmcmc_nf_results.csv', **kw),
+    }
+    if verbose:
+        for name, chain in chains.items():
+            print(name, "ESJD", esjd(chain))
+    return chains
+
+
+if __name__ == "__main__":
+    main()

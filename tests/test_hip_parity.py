@@ -587,3 +587,16 @@ def test_global_frequency_sweep(hip):
     assert out["esjd"].shape == (2, 4) and np.isfinite(out["resjd_mean"]).all()
     assert out["best_gf"] in (0, 0.5, 0.9, 1)
     assert out["esjd"][:, 2].mean() > out["esjd"][:, 0].mean()
+
+
+def test_example_script_runs_every_sampler(hip, tmp_path):
+    """examples/Mixture.py's __main__ (reference examples/Mixture.py:55-85) with all five runner calls enabled."""
+    from glabcmcmc_amd.examples import Mixture
+    chains = Mixture.main(num_ite=400, output_dir=str(tmp_path), verbose=False)
+    assert set(chains) == {"global", "glmcmc", "aglmcmc", "glmala", "glmcmc_nf"}
+    for name, c in chains.items():
+        assert c.shape == (400, 2) and c.dtype == torch.float32 and not c.is_cuda, name
+        assert torch.isfinite(c).all(), name
+        assert torch.equal(c[0], torch.zeros(2)), name
+    for f in ("global_mcmc_results.csv", "glmcmc_results.csv", "aglmcmc_results.csv", "glmala_results.csv", "glmcmc_nf_results.csv"):
+        assert (tmp_path / f).exists(), f
