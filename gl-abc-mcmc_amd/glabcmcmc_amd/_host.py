@@ -40,7 +40,16 @@ def finish(hist, chains, single, filelocation, csv_variant, verbose, return_devi
     out = hist.permute(0, 2, 1)                                    # (num_ite, C, d) view of the chain-major buffer
     if filelocation is not None:
         write_csv(out.reshape(out.shape[0], -1).cpu(), filelocation, csv_variant)
-    return out if return_device else out.cpu()
+    if return_device:
+        return out
+    if hist.numel() < (1 << 22):
+        return out.cpu()
+    # large histories: one contiguous DMA into pinned memory (57 GB/s against 5-8 GB/s for a pageable, permuting
+    # copy -- DESIGN.md section 5); the result is the (num_ite, C, d) view of that chain-major host buffer
+    host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
+    host.copy_(hist, non_blocking=True)
+    torch.cuda.synchronize(hist.device)
+    return host.permute(0, 2, 1)
 
 
 def write_csv(Theta_Re, filelocation, variant):

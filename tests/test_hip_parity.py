@@ -600,3 +600,19 @@ def test_example_script_runs_every_sampler(hip, tmp_path):
         assert torch.equal(c[0], torch.zeros(2)), name
     for f in ("global_mcmc_results.csv", "glmcmc_results.csv", "aglmcmc_results.csv", "glmala_results.csv", "glmcmc_nf_results.csv"):
         assert (tmp_path / f).exists(), f
+
+
+def test_large_history_comes_back_through_pinned_memory(hip):
+    """_host.finish: histories above 2^22 floats return as the (num_ite, C, d) view of a pinned chain-major buffer --
+    the same numbers as the device result."""
+    import glabcmcmc_amd as g
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    m = Mixture_set(0.3)
+    lp = g.DiagGaussian(2, loc=torch.zeros(1, 2), log_scale=torch.log(torch.tensor([0.35, 0.35])))
+    ip = g.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0]))
+    theta0 = torch.zeros(4096, 2)
+    y0 = torch.zeros(4096, 2) + 0.1
+    a = g.GLMCMC(m, 600, theta0, y0, lp, None, 0.7, ip, 5, seed=11)
+    b = g.GLMCMC(m, 600, theta0, y0, lp, None, 0.7, ip, 5, seed=11, return_device=True)
+    assert a.shape == (600, 4096, 2) and not a.is_cuda and a.is_pinned()
+    assert torch.equal(a, b.cpu())
