@@ -11,7 +11,7 @@ latency-bound, one call, no bucketing needed.
 import torch
 import torch.distributed as dist
 
-from . import _capi, engine
+from . import engine
 
 
 def shard_range(n_total, rank, world):
