@@ -324,7 +324,7 @@ typedef struct glabc_kde {
     float c_2pi;                   /* consts_out[dim + 1] */
 } glabc_kde;
 
-/* KernelDensity.log_prob, kernel_density.py:96-128: out[p] = logsumexp_s( ((-0.5 * sum_d ((pt_pd - x_sd)/bw_d)^2
+/* KernelDensity.log_prob, kernel_density.py:96-128: out[p] = logsumexp_s( ((-0.5 * sum_d ((pt_pd - x_sd)*(1/bw_d))^2
  * - c_2pi) - sum_log_bw) + log_w_s ), the inner float32 operations in the reference's order; the logsumexp is
  * max + log(sum exp(. - max)) with the sum taken exactly in 2^-40 fixed point (order-independent, so the lanes of a
  * wavefront can share one point).  pts is dimension-major [dim][n_points]. */

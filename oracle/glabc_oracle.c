@@ -1214,11 +1214,13 @@ ORACLE_API int oracle_kde_fit(const float* x, const float* w_raw, int64_t n, int
     return 0;
 }
 
+/* the difference is multiplied by the correctly rounded 1/bandwidth (the reference divides, :117; <= 1 ulp per term) */
 static float kde_log_term(const glabc_kde* k, const float* pt, int64_t s)
 {
     float t[GLABC_MAX_DIM];
     for (int d = 0; d < k->dim; ++d) {
-        float e = (pt[d] - k->x[d * k->n_samples + s]) / k->bandwidth[d];        /* :117 */
+        float inv = 1.0f / k->bandwidth[d];
+        float e = (pt[d] - k->x[d * k->n_samples + s]) * inv;                    /* :117 */
         t[d] = e * e;
     }
     float lk = -0.5f * aten_rowsum_f32(t, k->dim);                               /* :118 */
