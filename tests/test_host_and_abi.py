@@ -160,3 +160,17 @@ def test_runner_creates_output_dir(tmp_path):
     d = tmp_path / "a" / "b"
     r = g.MCMCRunner(object(), output_dir=str(d))
     assert d.is_dir() and r._path("x.csv") == os.path.join(str(d), "x.csv") and r._path(None) is None
+
+
+def test_integration_stub_matches_the_abi():
+    """The ctypes structures printed in INTEGRATION.md (the binding a maintainer of the reference would add) have the
+    sizes and field names of the tested declarations in _capi.py."""
+    from glabcmcmc_amd import _capi
+    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = src[src.index("import ctypes as C, numpy as np, torch"):src.index("lib = C.CDLL")]
+    ns = {}
+    exec(code, ns)
+    for name in ("Dist", "Model", "Chains", "Run"):
+        stub, real = ns[name], getattr(_capi, name)
+        assert C.sizeof(stub) == C.sizeof(real), name
+        assert [f[0] for f in stub._fields_] == [f[0] for f in real._fields_], name
