@@ -90,6 +90,7 @@ struct StepArgs {
     const double* tape_r;
     const float* tape_z;
     int32_t tape_nprop;
+    int32_t exact_index;          // GLABC_DEBUG_EXACT_INDEX
 };
 
 // ---- torch.sum association over a contiguous float32 row (GLMCMC.py:82) ---------
@@ -474,12 +475,34 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         gather_weights<L, N, NL>(wl, w);
         const float tot = aten_rowsum<N + 1>(w);                              // GLMCMC.py:82
         const double u_res = TAPE ? a.tape_r[tape_pos] : glabc_uniform_f64(hw[2], hw[3]);
+        // weight_sampling, GLMCMC.py:17-22: first k with u < sum_{j<=k} (double)(w_j / tot).  Fast pass: w_j * rcp(tot)
+        // is within 2.4e-7 relative of the float32 quotient (1 ulp of v_rcp_f32 + one rounding), so the partial sums
+        // are within 2.4e-7 of the reference's and the index can differ only if u lies that close to one of them;
+        // lanes where |u - partial sum| <= 1e-6 somewhere (or anything is NaN / inf) redo it with IEEE divisions.
         int ig = -1;
-        double run = 0.0;
+        bool sure = !a.exact_index;
+        {
+            const float rinv = __builtin_amdgcn_rcpf(tot);
+            double run = 0.0;
 #pragma unroll
-        for (int k = 0; k <= N; ++k) {
-            run += (double)(w[k] / tot);
-            ig = (ig < 0 && u_res < run) ? k : ig;                            // weight_sampling, GLMCMC.py:17-22
+            for (int k = 0; k <= N; ++k) {
+                run += (double)(w[k] * rinv);
+                const double gap = u_res - run;
+                sure = sure && (__builtin_fabs(gap) > 1e-6);
+                ig = (ig < 0 && gap < 0.0) ? k : ig;
+            }
+            // the reciprocal is only trusted where it is accurate: a denormal / huge / zero / non-finite total shows
+            // up as fast weights that do not sum to one
+            sure = sure && (run > 0.999) && (run < 1.001);
+        }
+        if (!sure) {
+            ig = -1;
+            double run = 0.0;
+#pragma unroll
+            for (int k = 0; k <= N; ++k) {
+                run += (double)(w[k] / tot);
+                ig = (ig < 0 && u_res < run) ? k : ig;
+            }
         }
         ig = ig < 0 ? 0 : ig;                                                 // None -> stay, GLMCMC.py:84
         const int il = group_bcast_i<L, 0>(acc_mh ? 1 : 0);
@@ -502,7 +525,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         for (int q = 0; q < YD; ++q) ny[q] = yy[0][q];
 #pragma unroll
         for (int r = 1; r < NL; ++r) {
-            if (slot == r) {
+            if (slot == r) {                      // (measured: these small masked blocks beat per-value selects)
 #pragma unroll
                 for (int q = 0; q < D; ++q) nt[q] = th[r][q];
 #pragma unroll

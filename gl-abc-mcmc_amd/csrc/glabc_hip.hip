@@ -541,6 +541,7 @@ static StepArgs<D, YD> pack_args(const glabc_model* m, const glabc_dist* local, 
         a.seed_hi = (uint32_t)(r->seed >> 32);
         a.step0 = r->step0;
         a.n_steps = r->n_steps;
+        a.exact_index = (r->debug_flags & GLABC_DEBUG_EXACT_INDEX) ? 1 : 0;
         a.gf = r->global_frequency;
         a.history = r->history;
         a.hist_stride = r->hist_stride;

@@ -20,6 +20,7 @@ SIM_ABS_GAUSS = 0
 SIM_GK = 1
 
 FLAG_LOCAL = 1
+DEBUG_EXACT_INDEX = 1          # glabc_run.debug_flags
 FLAG_TH64 = 2
 FLAG_LW64 = 4
 FLAG_HAS_GRAD = 8
@@ -177,7 +178,7 @@ class Run(C.Structure):
         ("moments", C.POINTER(Moments)),
         ("tape", C.POINTER(Tape)),
         ("lanes_per_chain", C.c_int32),
-        ("reserved", C.c_int32),
+        ("debug_flags", C.c_int32),
     ]
 
 

@@ -132,7 +132,7 @@ class Moments:
 
 
 def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0, seed, global_frequency, batch_size,
-              history=None, moments=None, steps_per_launch=None, lanes_per_chain=0):
+              history=None, moments=None, steps_per_launch=None, lanes_per_chain=0, debug_flags=0):
     """Advance `chains` by n_steps iterations with the C-ABI entry point `entry`
     ('glabc_glmcmc_steps' / 'glabc_globalmcmc_steps'), K iterations per launch.
 
@@ -157,6 +157,7 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
             run.global_frequency = float(global_frequency)
             run.batch_size = int(batch_size or 1)
             run.lanes_per_chain = int(lanes_per_chain)
+            run.debug_flags = int(debug_flags)
             if history is not None:
                 run.history = history[done].data_ptr()
                 run.hist_stride = chains.n

@@ -159,8 +159,14 @@ typedef struct glabc_run {
     const glabc_tape* tape;        /* NULL = Philox */
     int32_t lanes_per_chain;       /* launch geometry only, never changes results: 0 = choose from n_chains,
                                       or 1 / 2 / 4 lanes cooperating on one chain's batch_size proposals */
-    int32_t reserved;
+    int32_t debug_flags;           /* 0, or GLABC_DEBUG_* bits: execution strategy only, never changes results */
 } glabc_run;
+
+/* glabc_run.debug_flags: the iSIR index (GLMCMC.py:7-22) is normally found from reciprocal-multiplied weights and
+ * recomputed with the reference's IEEE divisions only when the resampling uniform lies within 1e-6 of a partial sum
+ * (the two cannot disagree otherwise: the fast quotients are within 2.4e-7 relative of the IEEE ones).  This bit takes
+ * the IEEE path always -- tests use it to show both paths give the same chains. */
+#define GLABC_DEBUG_EXACT_INDEX 1
 
 /* ---- entry points ------------------------------------------------------------ */
 

@@ -124,13 +124,16 @@ GLABC_HD float glabc_logf_normal(float x) { return glabc_logf_core(glabc_f2u(x),
 
 GLABC_HD float glabc_logf(float x)
 {
-    uint32_t ix = glabc_f2u(x);
-    float escale = 0.0f;
-    if (ix == 0u || ix == 0x80000000u) return -__builtin_inff();        /* log(+-0) = -inf */
-    if (ix >> 31) return __builtin_nanf("");                             /* log(<0) = nan (nan with sign bit too) */
-    if (ix >= 0x7f800000u) return x;                                     /* +inf, nan */
-    if (ix < 0x00800000u) { x = x * 0x1p23f; ix = glabc_f2u(x); escale = -23.0f; }
-    return glabc_logf_core(ix, escale);
+    /* branch-free: the core runs on whatever bits arrive (integer and IEEE arithmetic only) and the special cases
+     * are selected afterwards, in the order  +-0 -> -inf,  sign bit -> nan,  +inf / +nan -> x */
+    const uint32_t ix = glabc_f2u(x);
+    const int sub = ix < 0x00800000u;                                    /* +0 or positive subnormal */
+    const uint32_t jx = sub ? glabc_f2u(x * 0x1p23f) : ix;
+    float r = glabc_logf_core(jx, sub ? -23.0f : 0.0f);
+    r = (ix >= 0x7f800000u) ? x : r;                                     /* +inf, nan */
+    r = (ix >> 31) ? __builtin_nanf("") : r;                             /* log(<0) = nan (nan with sign bit too) */
+    r = ((ix << 1) == 0u) ? -__builtin_inff() : r;                       /* log(+-0) = -inf */
+    return r;
 }
 
 /* ---- f32 sqrt of x that is +-0 or finite with x >= 2^-64 ------------------------
@@ -159,11 +162,14 @@ GLABC_HD float glabc_sqrtf_normal(float x)
 /* ---- f32 exp ---------------------------------------------------------------
  * x = k ln2 + r, |r| <= ln2/2; exp r = 1 + r + r^2 Q(r); result scaled by 2^k in
  * two exact-or-once-rounded steps so the subnormal range rounds once. */
-GLABC_HD float glabc_expf(float x)
+GLABC_HD float glabc_expf(float x0)
 {
-    if (x > 88.72283935546875f) return __builtin_inff();
-    if (x < -104.0f) return 0.0f;
-    /* NaN falls through both tests and propagates through the arithmetic. */
+    /* Branch-free: the polynomial runs on the argument clamped to the finite range and the out-of-range results
+     * (+inf above 88.7228..., 0 below -104, NaN for NaN) are selected at the end -- six of these sit in every chain
+     * step, and early returns would cut the step into small scheduling regions. */
+    float x = x0 < -104.0f ? -104.0f : x0;
+    x = x > 88.72283935546875f ? 88.72283935546875f : x;
+    x = x0 != x0 ? 0.0f : x;
     float t = __builtin_fmaf(x, 0x1.715476p+0f, 12582912.0f);    /* round(x*log2e) in the low mantissa bits */
     float k = t - 12582912.0f;
     float r = __builtin_fmaf(k, -0x1.62e4p-1f, x);
@@ -174,11 +180,14 @@ GLABC_HD float glabc_expf(float x)
     q = __builtin_fmaf(q, r, 0x1.55548ep-3f);
     q = __builtin_fmaf(q, r, 0x1.fffff8p-2f);
     float p = __builtin_fmaf(q * r, r, r) + 1.0f;
-    int32_t ki = (int32_t)k;                            /* NaN -> unspecified int; p is NaN anyway */
+    int32_t ki = (int32_t)k;                            /* |k| <= 151 after the clamp */
     int32_t k1 = ki / 2, k2 = ki - k1;
     float s1 = glabc_u2f((uint32_t)(k1 + 127) << 23);
     float s2 = glabc_u2f((uint32_t)(k2 + 127) << 23);
-    return (p * s1) * s2;
+    float e = (p * s1) * s2;
+    e = x0 > 88.72283935546875f ? __builtin_inff() : e;
+    e = x0 < -104.0f ? 0.0f : e;
+    return x0 != x0 ? x0 : e;
 }
 
 /* ---- sin, cos of 2*pi*u for u in [0,1) ---------------------------------------

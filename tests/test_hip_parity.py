@@ -20,7 +20,7 @@ ENTRY = {"glmcmc": "glabc_glmcmc_steps", "globalmcmc": "glabc_globalmcmc_steps"}
 
 
 def hip_run(algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=0, steps_per_launch=None, moments=False,
-            step0=1, chains=None, history=True, lanes=0):
+            step0=1, chains=None, history=True, lanes=0, debug_flags=0):
     from glabcmcmc_amd import engine
     dev = torch.device("cuda", 0)
     if chains is None:
@@ -30,7 +30,7 @@ def hip_run(algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=0, step
     hist = torch.empty(T, chains.d, chains.n, dtype=torch.float32, device=dev) if history else None
     mom = engine.Moments(chains.n, chains.d, dev) if moments else None
     engine.run_steps(ENTRY[algo], model, local, glob, chains, T, step0, seed, gf, N, history=hist, moments=mom,
-                     steps_per_launch=steps_per_launch, lanes_per_chain=lanes)
+                     steps_per_launch=steps_per_launch, lanes_per_chain=lanes, debug_flags=debug_flags)
     torch.cuda.synchronize()
     return (hist.cpu().numpy() if history else None), chains, mom
 
@@ -616,3 +616,24 @@ def test_large_history_comes_back_through_pinned_memory(hip):
     b = g.GLMCMC(m, 600, theta0, y0, lp, None, 0.7, ip, 5, seed=11, return_device=True)
     assert a.shape == (600, 4096, 2) and not a.is_cuda and a.is_pinned()
     assert torch.equal(a, b.cpu())
+
+
+@pytest.mark.parametrize("eps,N,lanes", [(0.05, 5, 1), (0.3, 16, 1), (0.002, 3, 1), (0.05, 5, 2), (1e-4, 8, 4)])
+def test_fast_index_equals_ieee_index(hip, eps, N, lanes):
+    """The iSIR index from reciprocal-multiplied weights (with its IEEE-division fallback near a partial sum) gives the
+    chains of the always-IEEE path (GLABC_DEBUG_EXACT_INDEX) bit for bit -- including tiny epsilon, where most weights
+    underflow to 0 and the total can be 0 or denormal."""
+    from glabcmcmc_amd import _capi
+    cfg = dict(epsilon=eps, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(int(eps * 1e6) + N)
+    n, T = 8192, 300
+    theta0 = (rng.standard_normal((n, 2)) * 2).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2 * rng.standard_normal((n, 2))).astype(np.float32)
+    fast, cf, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, 77, 0.9, N, lanes=lanes)
+    exact, ce, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, 77, 0.9, N, lanes=lanes,
+                           debug_flags=_capi.DEBUG_EXACT_INDEX)
+    assert np.array_equal(bits(fast), bits(exact))
+    assert np.array_equal(bits(cf.log_w.cpu().numpy()), bits(ce.log_w.cpu().numpy()))
+    assert np.array_equal(cf.n_moves.cpu().numpy(), ce.n_moves.cpu().numpy())
+    assert int(cf.n_moves.sum()) > 0
