@@ -52,7 +52,8 @@ enum Variant { VAR_GENERIC = 0, VAR_GAUSS_UNIT = 1, VAR_TAPE = 2 };
 template <int D>
 struct DistArgs {
     int32_t kind;
-    int32_t unit_scale;          // DiagGaussian with every exp(log_scale) == 1.0f: (z-loc)/1 == z-loc
+    int32_t unit_scale;          // DiagGaussian with every log_scale == 0 and exp(log_scale) == 1.0f:
+                                 // (z-loc)/1 == z-loc and 0 + 0.5 e^2 == 0.5 e^2, bit for bit
     float c0;
     float p0[D], p1[D], p2[D];
 };
@@ -158,7 +159,7 @@ GLABC_DEV float dist_log_prob(const DistArgs<D>& g, const float (&z)[D])
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 float e = z[j] - g.p0[j];                    // == (z - loc) / 1.0f, bit for bit
-                t[j] = g.p1[j] + 0.5f * (e * e);
+                t[j] = 0.5f * (e * e);                       // == log_scale + 0.5 e^2 with log_scale = 0 (0.5 e^2 is never -0)
             }
         } else {
 #pragma unroll
@@ -177,13 +178,16 @@ GLABC_DEV float dist_log_prob(const DistArgs<D>& g, const float (&z)[D])
 }
 
 // log_p of forward() given its noise: DiagGaussian distribution.py:171-173, Uniform :78
-template <int D, bool KNOWN_GAUSS = false>
+template <int D, bool KNOWN_GAUSS_UNIT = false>
 GLABC_DEV float dist_forward_log_p(const DistArgs<D>& g, const float (&noise)[D])
 {
-    if (KNOWN_GAUSS || g.kind == GLABC_DIST_DIAG_GAUSS) {
+    if (KNOWN_GAUSS_UNIT || g.kind == GLABC_DIST_DIAG_GAUSS) {
         float t[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) t[j] = g.p1[j] + 0.5f * (noise[j] * noise[j]);
+        for (int j = 0; j < D; ++j) {
+            const float h = 0.5f * (noise[j] * noise[j]);
+            t[j] = KNOWN_GAUSS_UNIT ? h : g.p1[j] + h;       // log_scale = 0 in the unit variant
+        }
         return g.c0 - aten_rowsum<D>(t);
     }
     return g.c0;
@@ -374,7 +378,9 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         }
         const float ub = TAPE ? a.tape_u[2 * tape_pos] : glabc_uniform_f32(hw[0]);
         const float ua = TAPE ? a.tape_u[2 * tape_pos + 1] : glabc_uniform_f32(hw[1]);
-        log_u = glabc_logf(ua);                                               // GLMCMC.py:98 (u = 0 -> -inf)
+        // GLMCMC.py:98: log(u).  A Philox uniform is k 2^-24 -- zero or a normal float -- so the special cases of
+        // glabc_logf reduce to one select (same bits); a tape may hold anything
+        log_u = TAPE ? glabc_logf(ua) : ((ua == 0.0f) ? -__builtin_inff() : glabc_logf_normal(ua));
         is_global = ub < a.gf;                                                // GLMCMC.py:59 / GlobalMCMC.py:39
         if (ALGO == ALGO_GLMCMC && is_global) {
             if (c.flags & GLABC_FLAG_LOCAL) c.log_w = (c.prior + c.kern) - c.q;   // GLMCMC.py:60-64

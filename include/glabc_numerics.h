@@ -164,12 +164,10 @@ GLABC_HD float glabc_sqrtf_normal(float x)
  * two exact-or-once-rounded steps so the subnormal range rounds once. */
 GLABC_HD float glabc_expf(float x0)
 {
-    /* Branch-free: the polynomial runs on the argument clamped to the finite range and the out-of-range results
-     * (+inf above 88.7228..., 0 below -104, NaN for NaN) are selected at the end -- six of these sit in every chain
-     * step, and early returns would cut the step into small scheduling regions. */
-    float x = x0 < -104.0f ? -104.0f : x0;
-    x = x > 88.72283935546875f ? 88.72283935546875f : x;
-    x = x0 != x0 ? 0.0f : x;
+    /* Branch-free: the polynomial runs on the argument clamped to [-104, 88.7228...] (everything at or below -103.98
+     * already gives 0) and +inf above the range / NaN are selected at the end -- six of these sit in every chain step,
+     * and early returns would cut the step into small scheduling regions. */
+    float x = __builtin_fminf(__builtin_fmaxf(x0, -104.0f), 88.72283935546875f);      /* NaN -> -104 */
     float t = __builtin_fmaf(x, 0x1.715476p+0f, 12582912.0f);    /* round(x*log2e) in the low mantissa bits */
     float k = t - 12582912.0f;
     float r = __builtin_fmaf(k, -0x1.62e4p-1f, x);
@@ -184,9 +182,8 @@ GLABC_HD float glabc_expf(float x0)
     int32_t k1 = ki / 2, k2 = ki - k1;
     float s1 = glabc_u2f((uint32_t)(k1 + 127) << 23);
     float s2 = glabc_u2f((uint32_t)(k2 + 127) << 23);
-    float e = (p * s1) * s2;
+    float e = (p * s1) * s2;                            /* exp(-104) = 0 already: only overflow and NaN need a select */
     e = x0 > 88.72283935546875f ? __builtin_inff() : e;
-    e = x0 < -104.0f ? 0.0f : e;
     return x0 != x0 ? x0 : e;
 }
 
