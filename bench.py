@@ -222,9 +222,8 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    if world > 1:
-        gather_chain_stats(mom, world, via=cdev)       # untimed: lets RCCL set up the all-gather's channels once
-    barrier()
+    gather_chain_stats(mom, world, via=cdev)           # untimed: RCCL sets up the all-gather's channels, torch loads its
+    barrier()                                          # reduction kernels -- once, outside the measurement
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in ev:

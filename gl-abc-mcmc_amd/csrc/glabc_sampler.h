@@ -15,7 +15,9 @@ namespace glabc {
 
 constexpr int BLOCK = 64;      // one wavefront per workgroup: 65 536 chains x L lanes spread evenly over 1024 SIMDs
 
-template <int ALGO, int D, int YD, int N, int L, int VAR>
+// SCHED only names the object the instantiation lives in: the same source is compiled twice, with the default
+// (occupancy-oriented) instruction schedule and with -amdgpu-sched-strategy=max-ilp (see the Makefile and run_sampler)
+template <int ALGO, int D, int YD, int N, int L, int VAR, int SCHED>
 __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D, YD> a)
 {
     const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -109,9 +111,11 @@ __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D, YD> a)
     }
 }
 
-// host-side launcher of one theta_dim; defined in glabc_sampler_dim.hip (one TU per D).
+// host-side launcher of one theta_dim; defined in glabc_sampler_dim.hip (one TU per D and schedule).
 // lanes = lanes per chain actually compiled for (1, 2 or 4).  Returns a glabc_status.
-template <int D, int YD>
+// SCHED_ILP objects hold the one-lane-per-chain kernels only (the schedule for launches of at most two waves per SIMD).
+constexpr int SCHED_DEFAULT = 0, SCHED_ILP = 1;
+template <int D, int YD, int SCHED>
 int launch_sampler_dim(int algo, int n_batch, int lanes, const StepArgs<D, YD>& a, hipStream_t stream);
 
 }  // namespace glabc

@@ -8,6 +8,9 @@
 #ifndef GLABC_YDIM
 #define GLABC_YDIM GLABC_DIM
 #endif
+#ifndef GLABC_SCHED
+#define GLABC_SCHED 0
+#endif
 
 namespace glabc {
 
@@ -26,30 +29,34 @@ static int launch_one(const StepArgs<D, YD>& a, hipStream_t s)
     const unsigned grid = (unsigned)((lanes + BLOCK - 1) / BLOCK);
     if (a.tape_u) {
         if constexpr (L == 1)
-            hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, 1, VAR_TAPE>), dim3(grid), dim3(BLOCK), 0, s, a);
+            hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, 1, VAR_TAPE, GLABC_SCHED>), dim3(grid), dim3(BLOCK), 0, s, a);
         else
             return GLABC_ERR_ARG;
     } else if (YD == D && gauss_unit<D, YD>(a))
-        hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, L, (YD == D ? VAR_GAUSS_UNIT : VAR_GENERIC)>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, L, (YD == D ? VAR_GAUSS_UNIT : VAR_GENERIC), GLABC_SCHED>), dim3(grid), dim3(BLOCK), 0, s, a);
     else
-        hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, L, VAR_GENERIC>), dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, L, VAR_GENERIC, GLABC_SCHED>), dim3(grid), dim3(BLOCK), 0, s, a);
     return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
 }
 
 template <int D, int YD, int N>
 static int launch_lanes(int lanes, const StepArgs<D, YD>& a, hipStream_t s)
 {
+#if GLABC_SCHED == 0
     if constexpr (N >= 2) {
         if (lanes == 2) return launch_one<ALGO_GLMCMC, D, YD, N, 2>(a, s);
     }
     if constexpr (N >= 3) {
         if (lanes == 4) return launch_one<ALGO_GLMCMC, D, YD, N, 4>(a, s);
     }
+#else
+    if (lanes != 1) return GLABC_ERR_ARG;                       // the max-ilp objects hold one-lane kernels only
+#endif
     return launch_one<ALGO_GLMCMC, D, YD, N, 1>(a, s);
 }
 
 template <>
-int launch_sampler_dim<GLABC_DIM, GLABC_YDIM>(int algo, int n_batch, int lanes, const StepArgs<GLABC_DIM, GLABC_YDIM>& a,
+int launch_sampler_dim<GLABC_DIM, GLABC_YDIM, GLABC_SCHED>(int algo, int n_batch, int lanes, const StepArgs<GLABC_DIM, GLABC_YDIM>& a,
                                               hipStream_t s)
 {
     constexpr int D = GLABC_DIM, YD = GLABC_YDIM;
