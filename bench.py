@@ -255,30 +255,30 @@ def main():
         esjd_all = stats["esjd"]
         ok = torch.isfinite(esjd_all)
         # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
-        # read correction applied) for exactly this configuration: profiles/r01_d_pmc_summary.json
+        # read correction applied) for exactly this configuration: profiles/r01_f_pmc_summary.json
         traffic, valu = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_d_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_f_pmc_summary.json")) as f:
                 pmc = json.load(f)
             if args.workload == "glmcmc" and pmc["config"] == {"chains": n, "iters_per_launch": K,
                                                                "history": not args.no_history}:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]["total"]
                 per_step = pmc["derived"]["valu_insts_per_wave_step"]
                 wave_insts_per_s = per_step * (n / 64.0) * K / (kernel_ms * 1e-3)      # live kernel time x counted instructions
-                valu = {"source": "profiles/r01_d_pmc_summary.json (rocprofv3 --pmc, round 1) + this run's kernel time",
+                valu = {"source": "profiles/r01_f_pmc_summary.json (rocprofv3 --pmc, round 1) + this run's kernel time",
                         "valu_insts_per_wave_step": per_step,
                         "valu_active_fraction": pmc["derived"]["valu_active_fraction"],
                         "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
                         "wave_insts_per_s": wave_insts_per_s,
                         # measured ceilings (tools/ubench/valu_peak.hip): a SIMD retires 1.0e9 simple wave64
                         # VALU ops/s (v_add_u32, v_xor_b32, v_mul_f32; >= 2 waves/SIMD), and THIS kernel's instruction mix
-                        # (v_pk_* 5.4, v_mad_u64_u32 4.2, v_fma_f32 3.2 cycles) saturates at 6.7e11 wave-insts/s on the
+                        # (v_pk_* 5.4, v_mad_u64_u32 4.2, v_fma_f32 3.2 cycles) saturates at 6.5e11 wave-insts/s on the
                         # chip (524 288 chains = 8 waves/SIMD); one wave per SIMD -- the 65 536-chain shape -- cannot
                         # issue faster than one instruction per ~4.7 cycles.
                         "issue_peak_wave_insts_per_s": 1024 * 1.0e9,
                         "issue_frac": wave_insts_per_s / (1024 * 1.0e9),
-                        "mix_saturated_wave_insts_per_s": 6.7e11,
-                        "mix_frac": wave_insts_per_s / 6.7e11}
+                        "mix_saturated_wave_insts_per_s": 6.5e11,
+                        "mix_frac": wave_insts_per_s / 6.5e11}
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -308,7 +308,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_chain_step": algo_bytes / (n * K),
                          "valu": valu,
-                         "note": "the step is VALU-issue-bound, not HBM-bound: ~1450 vector instructions per chain-"
+                         "note": "the step is VALU-issue-bound, not HBM-bound: ~1360 vector instructions per chain-"
                                  "step against 8 algorithmic bytes (Philox + Box-Muller + densities); see DESIGN.md"},
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "glmcmc":
