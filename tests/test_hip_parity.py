@@ -637,3 +637,23 @@ def test_fast_index_equals_ieee_index(hip, eps, N, lanes):
     assert np.array_equal(bits(cf.log_w.cpu().numpy()), bits(ce.log_w.cpu().numpy()))
     assert np.array_equal(cf.n_moves.cpu().numpy(), ce.n_moves.cpu().numpy())
     assert int(cf.n_moves.sum()) > 0
+
+
+@pytest.mark.parametrize("y_obs,n", [((1e-3, 2.0), 3000), ((0.0, 0.0), 3000), ((1.5, 1.5), 200000)])
+def test_unit_gaussian_variant_and_its_fallback(hip, oracle, y_obs, n):
+    """The branch-free unit-Gaussian kernel variant (lean square root, no +0 log-scale terms) needs every
+    |y_obs_j| >= 2^-6; other observations take the generic kernels.  Both against the oracle, bit for bit -- the large
+    case (more than two waves per SIMD) also exercises the default-schedule object."""
+    cfg = dict(epsilon=0.2, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    for j in range(2):
+        model.y_obs[j] = y_obs[j]
+    rng = np.random.default_rng(5)
+    T = 60 if n < 100000 else 12
+    theta0 = (rng.standard_normal((n, 2)) * 0.5).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, 2))).astype(np.float32)
+    hist, chains, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, 9, 0.8, 5)
+    hh, hc, _ = oracle_run(oracle, "glmcmc", model, local, glob, theta0, y0, T, 9, 0.8, 5)
+    assert np.array_equal(bits(hist), bits(hh))
+    assert_same_state(chains, hc, True)
+    assert hc.n_moves.sum() > 0
