@@ -485,25 +485,27 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         gather_weights<L, N, NL>(wl, w);
         const float tot = aten_rowsum<N + 1>(w);                              // GLMCMC.py:82
         const double u_res = TAPE ? a.tape_r[tape_pos] : glabc_uniform_f64(hw[2], hw[3]);
-        // weight_sampling, GLMCMC.py:17-22: first k with u < sum_{j<=k} (double)(w_j / tot).  Fast pass: w_j * rcp(tot)
-        // is within 2.4e-7 relative of the float32 quotient (1 ulp of v_rcp_f32 + one rounding), so the partial sums
-        // are within 2.4e-7 of the reference's and the index can differ only if u lies that close to one of them;
-        // lanes where |u - partial sum| <= 1e-6 somewhere (or anything is NaN / inf) redo it with IEEE divisions.
+        // weight_sampling, GLMCMC.py:17-22: first k with u < sum_{j<=k} (double)(w_j / tot).  Fast pass in float32:
+        // w_j * rcp(tot) is within 2.4e-7 relative of the float32 quotient (1 ulp of v_rcp_f32 + one rounding) and a
+        // float32 running sum of <= 17 such terms adds <= 1e-6, so the partial sums are within 1.3e-6 of the reference's
+        // and the index can differ only if u lies that close to one of them; lanes where |u - partial sum| <= 4e-6
+        // somewhere (or anything is NaN / inf) redo it the reference's way: IEEE divisions, double sums.
         int ig = -1;
         bool sure = !a.exact_index;
         {
             const float rinv = __builtin_amdgcn_rcpf(tot);
-            double run = 0.0;
+            const float u32 = (float)u_res;
+            float run = 0.0f;
 #pragma unroll
             for (int k = 0; k <= N; ++k) {
-                run += (double)(w[k] * rinv);
-                const double gap = u_res - run;
-                sure = sure && (__builtin_fabs(gap) > 1e-6);
-                ig = (ig < 0 && gap < 0.0) ? k : ig;
+                run += w[k] * rinv;
+                const float gap = u32 - run;
+                sure = sure && (__builtin_fabsf(gap) > 4e-6f);
+                ig = (ig < 0 && gap < 0.0f) ? k : ig;
             }
             // the reciprocal is only trusted where it is accurate: a denormal / huge / zero / non-finite total shows
             // up as fast weights that do not sum to one
-            sure = sure && (run > 0.999) && (run < 1.001);
+            sure = sure && (run > 0.999f) && (run < 1.001f);
         }
         if (!sure) {
             ig = -1;

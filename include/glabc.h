@@ -162,10 +162,10 @@ typedef struct glabc_run {
     int32_t debug_flags;           /* 0, or GLABC_DEBUG_* bits: execution strategy only, never changes results */
 } glabc_run;
 
-/* glabc_run.debug_flags: the iSIR index (GLMCMC.py:7-22) is normally found from reciprocal-multiplied weights and
- * recomputed with the reference's IEEE divisions only when the resampling uniform lies within 1e-6 of a partial sum
- * (the two cannot disagree otherwise: the fast quotients are within 2.4e-7 relative of the IEEE ones).  This bit takes
- * the IEEE path always -- tests use it to show both paths give the same chains. */
+/* glabc_run.debug_flags: the iSIR index (GLMCMC.py:7-22) is normally found from float32 reciprocal-multiplied
+ * weights and recomputed the reference's way (IEEE divisions, double partial sums) only when the resampling uniform
+ * lies within 4e-6 of a partial sum (the two cannot disagree otherwise: the fast partial sums are within 1.3e-6 of
+ * the reference's).  This bit takes the reference's path always -- tests use it to show both give the same chains. */
 #define GLABC_DEBUG_EXACT_INDEX 1
 
 /* ---- entry points ------------------------------------------------------------ */
