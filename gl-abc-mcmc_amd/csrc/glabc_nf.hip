@@ -183,10 +183,10 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
         auto apply = [&](int q, float shift, float log_s, float t0, float t1) {
             if (INVERSE) {
                 z0[q] = t0;
-                z1[q] = (t1 - shift) * glabc_expf(-log_s);
+                z1[q] = (t1 - shift) * glabc_expf_b(-log_s);
                 lq[q] = lq[q] + (-log_s);
             } else {
-                const float nz = z1[q] * glabc_expf(log_s) + shift;
+                const float nz = z1[q] * glabc_expf_b(log_s) + shift;
                 lq[q] = lq[q] - log_s;                                 // log_q -= log_det
                 z1[q] = z0[q];                                         // Permute(2, 'swap')
                 z0[q] = nz;

@@ -162,12 +162,8 @@ GLABC_HD float glabc_sqrtf_normal(float x)
 /* ---- f32 exp ---------------------------------------------------------------
  * x = k ln2 + r, |r| <= ln2/2; exp r = 1 + r + r^2 Q(r); result scaled by 2^k in
  * two exact-or-once-rounded steps so the subnormal range rounds once. */
-GLABC_HD float glabc_expf(float x0)
+GLABC_HD float glabc_expf_core(float x)            /* x in [-104, 88.7228...] */
 {
-    /* Branch-free: the polynomial runs on the argument clamped to [-104, 88.7228...] (everything at or below -103.98
-     * already gives 0) and +inf above the range / NaN are selected at the end -- six of these sit in every chain step,
-     * and early returns would cut the step into small scheduling regions. */
-    float x = __builtin_fminf(__builtin_fmaxf(x0, -104.0f), 88.72283935546875f);      /* NaN -> -104 */
     float t = __builtin_fmaf(x, 0x1.715476p+0f, 12582912.0f);    /* round(x*log2e) in the low mantissa bits */
     float k = t - 12582912.0f;
     float r = __builtin_fmaf(k, -0x1.62e4p-1f, x);
@@ -178,13 +174,32 @@ GLABC_HD float glabc_expf(float x0)
     q = __builtin_fmaf(q, r, 0x1.55548ep-3f);
     q = __builtin_fmaf(q, r, 0x1.fffff8p-2f);
     float p = __builtin_fmaf(q * r, r, r) + 1.0f;
-    int32_t ki = (int32_t)k;                            /* |k| <= 151 after the clamp */
+    int32_t ki = (int32_t)k;                            /* |k| <= 151 */
     int32_t k1 = ki / 2, k2 = ki - k1;
     float s1 = glabc_u2f((uint32_t)(k1 + 127) << 23);
     float s2 = glabc_u2f((uint32_t)(k2 + 127) << 23);
-    float e = (p * s1) * s2;                            /* exp(-104) = 0 already: only overflow and NaN need a select */
+    return (p * s1) * s2;
+}
+
+GLABC_HD float glabc_expf(float x0)
+{
+    /* Branch-free: the polynomial runs on the argument clamped to [-104, 88.7228...] (everything at or below -103.98
+     * already gives 0) and +inf above the range / NaN are selected at the end -- six of these sit in every chain step,
+     * and early returns would cut the step into small scheduling regions. */
+    float x = __builtin_fminf(__builtin_fmaxf(x0, -104.0f), 88.72283935546875f);      /* NaN -> -104 */
+    float e = glabc_expf_core(x);                       /* exp(-104) = 0 already: only overflow and NaN need a select */
     e = x0 > 88.72283935546875f ? __builtin_inff() : e;
     return x0 != x0 ? x0 : e;
+}
+
+/* The same function with early returns instead of selects (same bits for every input, tests/test_numerics.py): the
+ * form for code whose registers are scarcer than its branches (the MFMA kernel of glabc_nf.hip). */
+GLABC_HD float glabc_expf_b(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -104.0f) return 0.0f;
+    return glabc_expf_core(x);
 }
 
 /* ---- sin, cos of 2*pi*u for u in [0,1) ---------------------------------------

@@ -1430,6 +1430,11 @@ ORACLE_API void oracle_expf_v(const float* x, int64_t n, float* out)
     for (int64_t i = 0; i < n; ++i) out[i] = glabc_expf(x[i]);
 }
 
+ORACLE_API void oracle_expf_b_v(const float* x, int64_t n, float* out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = glabc_expf_b(x[i]);
+}
+
 ORACLE_API void oracle_logf_v(const float* x, int64_t n, float* out)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = glabc_logf(x[i]);

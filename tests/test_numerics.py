@@ -97,3 +97,21 @@ def test_normal_pair_statistics(oracle):
     assert abs((z ** 3).mean()) < 1e-2 and abs((z ** 4).mean() - 3) < 3e-2
     assert abs(np.mean(z0.astype(np.float64) * z1)) < 2e-3
     assert np.abs(z).max() < 6.8
+
+
+def test_expf_select_form_equals_early_return_form(oracle):
+    """glabc_expf (clamp + selects, the chain step's form) and glabc_expf_b (early returns, the MFMA kernel's form)
+    return the same bits everywhere: a dense sweep of the finite range, both range ends, specials."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([
+        rng.uniform(-110, 92, 2_000_000).astype(np.float32),
+        np.linspace(-104.5, -103.5, 200001, dtype=np.float32), np.linspace(88.0, 89.5, 200001, dtype=np.float32),
+        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 88.72283935546875, -104.0, 1e30, -1e30, 1e-45, -1e-45],
+                 dtype=np.float32),
+        rng.integers(0, 2 ** 32, 2_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    a, b = np.empty_like(x), np.empty_like(x)
+    oracle.oracle_expf_v(x.ctypes.data, x.size, a.ctypes.data)
+    oracle.oracle_expf_b_v(x.ctypes.data, x.size, b.ctypes.data)
+    nan = np.isnan(a)
+    assert np.array_equal(nan, np.isnan(b)) and np.array_equal(nan, np.isnan(x))
+    assert np.array_equal(a[~nan].view(np.uint32), b[~nan].view(np.uint32))
