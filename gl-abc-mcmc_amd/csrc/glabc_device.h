@@ -68,6 +68,8 @@ struct StepArgs {
     float noise_loc[YD], noise_scale[YD];
     float y_obs[YD];
     float kern_log_scale, kern_scale, kern_c0;
+    float kern_rinv;             // RN(1/kern_scale) if x/kern_scale == fma(fma(-q, s, x), rinv, q), q = x*rinv, was verified
+                                 // on the host for every float32 significand of x (verified_reciprocal); else 0
     // proposals: local increment (GLMCMC.py:91) and global / importance (GLMCMC.py:66, GlobalMCMC.py:40)
     DistArgs<D> local, global;
     // chains
@@ -260,7 +262,18 @@ GLABC_DEV float model_log_kernel(const StepArgs<D, YD>& a, const float (&y)[YD])
     }
     const float ss = aten_rowsum<YD>(t);
     float dis = LEAN_SQRT ? glabc_sqrtf_normal(ss) : __builtin_sqrtf(ss);
-    float e = (dis - 0.0f) / a.kern_scale;
+    float e;
+    if constexpr (LEAN_SQRT) {
+        // dis / kern_scale in three instructions instead of the twelve of an IEEE division: with r = RN(1/s) the
+        // residual-corrected product is the correctly rounded quotient for EVERY significand of dis -- checked
+        // exhaustively on the host for this s before the variant is chosen; dis is 0 or in [2^-31, 2^64] here and s
+        // in [2^-20, 2^20], so nothing under- or overflows and the binade does not matter.  (dis = inf / nan gives nan
+        // instead of inf: such a candidate has weight 0 and is never accepted either way.)
+        const float q = dis * a.kern_rinv;
+        e = __builtin_fmaf(__builtin_fmaf(-q, a.kern_scale, dis), a.kern_rinv, q);
+    } else {
+        e = (dis - 0.0f) / a.kern_scale;
+    }
     return a.kern_c0 - (a.kern_log_scale + 0.5f * (e * e));
 }
 

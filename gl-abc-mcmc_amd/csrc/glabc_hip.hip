@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 
 #include "glabc_mala.h"
 #include "glabc_sampler.h"
@@ -509,6 +510,39 @@ static DistArgs<D> pack_dist(const glabc_dist* g)
     return o;
 }
 
+// RN(1/s) if the three-instruction division of model_log_kernel is exact for this divisor, else 0.  The check runs the
+// device's instruction sequence (IEEE mul + two fused multiply-adds) over all 2^23 significands of the dividend and
+// compares with the IEEE quotient (~7 ms, remembered per divisor); powers of two scale every step exactly.
+__attribute__((target("fma"))) static bool reciprocal_division_exact(float s, float r)
+{
+    for (uint32_t m = 0; m < (1u << 23); ++m) {
+        const uint32_t bits = 0x3f800000u | m;
+        float x;
+        std::memcpy(&x, &bits, sizeof x);
+        const float q = x * r;
+        if (__builtin_fmaf(__builtin_fmaf(-q, s, x), r, q) != x / s) return false;
+    }
+    return true;
+}
+
+static float verified_reciprocal(float s)
+{
+    if (!(s >= 0x1p-20f && s <= 0x1p20f) || !__builtin_cpu_supports("fma")) return 0.0f;
+    static std::mutex lock;
+    static float seen_s[16], seen_r[16];
+    static int n_seen = 0, next = 0;
+    std::lock_guard<std::mutex> guard(lock);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen_s[i] == s) return seen_r[i];
+    const float r = 1.0f / s;
+    const float out = reciprocal_division_exact(s, r) ? r : 0.0f;
+    seen_s[next] = s;
+    seen_r[next] = out;
+    next = (next + 1) % 16;
+    if (n_seen < 16) ++n_seen;
+    return out;
+}
+
 template <int D, int YD = D>
 static StepArgs<D, YD> pack_args(const glabc_model* m, const glabc_dist* local, const glabc_dist* global,
                                  const glabc_chains* c, const glabc_run* r)
@@ -526,6 +560,7 @@ static StepArgs<D, YD> pack_args(const glabc_model* m, const glabc_dist* local, 
     a.kern_log_scale = m->kern_log_scale;
     a.kern_scale = m->kern_scale;
     a.kern_c0 = m->kern_c0;
+    a.kern_rinv = (local && YD == D) ? verified_reciprocal(m->kern_scale) : 0.0f;      // sampler launches only
     a.local = pack_dist<D>(local ? local : global);
     a.global = pack_dist<D>(global);
     a.theta = c->theta;
