@@ -344,7 +344,9 @@ struct Chain {
     float prior;      // prior_log_prob(theta)         (cache of a pure function of the state)
     float kern;       // calculate_log_kernel(y)       (cache)
     float q;          // global/importance log_prob(theta)  (cache)
-    float log_w;      // log_weight_old, GLMCMC.py:53-55
+    float log_w;      // log_weight_old, GLMCMC.py:53-55 -- stale after an accepted local move until the next global step
+    float lw_cur;     // (prior + kern) - q of the CURRENT state: what GLMCMC.py:60-64 will assign to log_weight_old (cache)
+    float w_cur;      // exp(lw_cur), NaN -> 0: the current state's iSIR weight, GLMCMC.py:75-81 (cache)
     uint32_t flags;
     uint32_t n_moves;
 };
@@ -400,7 +402,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         log_u = TAPE ? glabc_logf(ua) : ((ua == 0.0f) ? -__builtin_inff() : glabc_logf_normal(ua));
         is_global = ub < a.gf;                                                // GLMCMC.py:59 / GlobalMCMC.py:39
         if (ALGO == ALGO_GLMCMC && is_global) {
-            if (c.flags & GLABC_FLAG_LOCAL) c.log_w = (c.prior + c.kern) - c.q;   // GLMCMC.py:60-64
+            if (c.flags & GLABC_FLAG_LOCAL) c.log_w = c.lw_cur;                   // GLMCMC.py:60-64
             c.flags &= ~GLABC_FLAG_LOCAL;                                         // GLMCMC.py:65
         }
     };
@@ -466,7 +468,20 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
             const float t = p0 + p2 * e[q];                                   // distribution.py:170 / :77
             th[r][q] = loc ? (t + c.theta[q]) : t;                            // GLMCMC.py:91
         }
-        const float lq = dist_forward_log_p<D, GU>(a.global, e);              // unused by the local move
+        // log q of the proposal under the global distribution: from its noise (forward(), GLMCMC.py:66) for an iSIR
+        // candidate; for GLMCMC's local move q(theta') itself, so that lw / wl of slot 0 are the log-weight and weight
+        // the proposed state will carry if it is accepted (what GLMCMC.py:60-64 computes at the next global step)
+        float lq;
+        if constexpr (ALGO == ALGO_GLMCMC && GU) {
+            float v[D];                                                       // both are c0 - sum 0.5 v^2 in the unit variant
+#pragma unroll
+            for (int q = 0; q < D; ++q) v[q] = loc ? (th[r][q] - a.global.p0[q]) : e[q];
+            lq = dist_forward_log_p<D, GU>(a.global, v);
+        } else if constexpr (ALGO == ALGO_GLMCMC) {
+            lq = loc ? dist_log_prob<D, GU>(a.global, th[r]) : dist_forward_log_p<D, GU>(a.global, e);
+        } else {
+            lq = dist_forward_log_p<D, GU>(a.global, e);                      // unused by the local move
+        }
         model_simulate<D, YD>(a, th[r], s, yy[r]);
         pr[r] = dist_log_prob<D, GU>(a.prior, th[r]);
         kk[r] = model_log_kernel<D, YD, GU>(a, yy[r]);
@@ -491,10 +506,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
     int ind;
     if constexpr (ALGO == ALGO_GLMCMC) {
         float w[N + 1];
-        {
-            const float v = glabc_expf(c.log_w);
-            w[0] = (v != v) ? 0.0f : v;
-        }
+        w[0] = c.w_cur;                                                       // exp(log_weight_old), GLMCMC.py:75-81
         gather_weights<L, N, NL>(wl, w);
         const float tot = aten_rowsum<N + 1>(w);                              // GLMCMC.py:82
         const double u_res = TAPE ? a.tape_r[tape_pos] : glabc_uniform_f64(hw[2], hw[3]);
@@ -543,7 +555,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         const int slot = (ind - 1) / L;
         // this lane's candidate in the winning slot (conditional moves over the unrolled slots keep
         // everything in VGPRs; a run-time array index would be promoted to LDS / scratch)
-        float nt[D], ny[YD], nlw = lw[0], npr = pr[0], nkk = kk[0];
+        float nt[D], ny[YD], nlw = lw[0], npr = pr[0], nkk = kk[0], nw = (ALGO == ALGO_GLMCMC) ? wl[0] : 0.0f;
 #pragma unroll
         for (int q = 0; q < D; ++q) nt[q] = th[0][q];
 #pragma unroll
@@ -558,6 +570,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
                 nlw = lw[r];
                 npr = pr[r];
                 nkk = kk[r];
+                if (ALGO == ALGO_GLMCMC) nw = wl[r];
             }
         }
 #pragma unroll
@@ -567,6 +580,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         nlw = group_get_dyn<L>(nlw, owner);
         npr = group_get_dyn<L>(npr, owner);
         nkk = group_get_dyn<L>(nkk, owner);
+        if (ALGO == ALGO_GLMCMC) nw = group_get_dyn<L>(nw, owner);
         if (moved) {
 #pragma unroll
             for (int q = 0; q < D; ++q) c.theta[q] = nt[q];
@@ -576,6 +590,8 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
             c.kern = nkk;
             c.q = dist_log_prob<D, GU>(a.global, c.theta);
             if (ALGO == ALGO_GLMCMC) {
+                c.lw_cur = nlw;
+                c.w_cur = nw;
                 if (is_global)
                     c.log_w = nlw;                                            // GLMCMC.py:86
                 else

@@ -37,6 +37,11 @@ __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D, YD> a)
     c.flags = (ALGO == ALGO_GLMCMC) ? a.flags[i] : 0u;
     c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
     refresh_cache<D, YD>(a, c);
+    c.lw_cur = (c.flags & GLABC_FLAG_LOCAL) ? (c.prior + c.kern) - c.q : c.log_w;          // GLMCMC.py:60-64
+    {
+        const float v = glabc_expf(c.lw_cur);
+        c.w_cur = (v != v) ? 0.0f : v;                                                      // GLMCMC.py:78-81
+    }
 
     constexpr int TRI = D * (D + 1) / 2;
     const bool mom = a.sum_theta != nullptr;
