@@ -68,6 +68,7 @@ struct StepArgs {
     float noise_loc[YD], noise_scale[YD];
     float y_obs[YD];
     float kern_log_scale, kern_scale, kern_c0;
+    int32_t y_obs_away;          // every |y_obs_j| >= 2^-6: a sum of squared differences is 0 or >= 2^-62 (lean sqrt domain)
     float kern_rinv;             // RN(1/kern_scale) if x/kern_scale == fma(fma(-q, s, x), rinv, q), q = x*rinv, was verified
                                  // on the host for every float32 significand of x (verified_reciprocal); else 0
     // proposals: local increment (GLMCMC.py:91) and global / importance (GLMCMC.py:66, GlobalMCMC.py:40)

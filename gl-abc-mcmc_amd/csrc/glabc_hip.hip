@@ -557,6 +557,8 @@ static StepArgs<D, YD> pack_args(const glabc_model* m, const glabc_dist* local, 
         a.noise_scale[j] = m->noise.p2[j];
         a.y_obs[j] = m->y_obs[j];
     }
+    a.y_obs_away = 1;
+    for (int j = 0; j < YD; ++j) a.y_obs_away = a.y_obs_away && (std::fabs(m->y_obs[j]) >= 0x1p-6f);
     a.kern_log_scale = m->kern_log_scale;
     a.kern_scale = m->kern_scale;
     a.kern_c0 = m->kern_c0;

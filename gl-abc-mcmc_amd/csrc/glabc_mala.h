@@ -122,7 +122,7 @@ GLABC_DEV float model_discrepancy(const StepArgs<D>& a, const float (&y)[D])
         float d = y[j] - a.y_obs[j];
         t[j] = d * d;
     }
-    return __builtin_sqrtf(aten_rowsum<D>(t));
+    return __builtin_sqrtf(aten_rowsum<D>(t));      // (a run-time switch to the lean square root measured slower here)
 }
 
 template <int D>

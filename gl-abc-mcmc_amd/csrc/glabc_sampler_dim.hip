@@ -18,8 +18,7 @@ namespace glabc {
 template <int D, int YD>
 static bool gauss_unit(const StepArgs<D, YD>& a)
 {
-    bool y_obs_away_from_zero = true;           // lets the variant use the lean square root (model_log_kernel)
-    for (int j = 0; j < YD; ++j) y_obs_away_from_zero = y_obs_away_from_zero && (__builtin_fabsf(a.y_obs[j]) >= 0x1p-6f);
+    const bool y_obs_away_from_zero = a.y_obs_away != 0;    // lets the variant use the lean square root (model_log_kernel)
     return a.prior.kind == GLABC_DIST_DIAG_GAUSS && a.prior.unit_scale && a.global.kind == GLABC_DIST_DIAG_GAUSS &&
            a.global.unit_scale && a.local.kind == GLABC_DIST_DIAG_GAUSS && y_obs_away_from_zero && a.kern_rinv != 0.0f;
 }
