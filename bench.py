@@ -308,7 +308,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_chain_step": algo_bytes / (n * K),
                          "valu": valu,
-                         "note": "the step is VALU-issue-bound, not HBM-bound: ~1320 vector instructions per chain-"
+                         "note": "the step is VALU-issue-bound, not HBM-bound: ~1260 vector instructions per chain-"
                                  "step against 8 algorithmic bytes (Philox + Box-Muller + densities); see DESIGN.md"},
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "glmcmc":
