@@ -272,13 +272,13 @@ def main():
                         "wave_insts_per_s": wave_insts_per_s,
                         # measured ceilings (tools/ubench/valu_peak.hip): a SIMD retires 1.0e9 simple wave64
                         # VALU ops/s (v_add_u32, v_xor_b32, v_mul_f32; >= 2 waves/SIMD), and THIS kernel's instruction mix
-                        # (v_pk_* 5.4, v_mad_u64_u32 4.2, v_fma_f32 3.2 cycles) saturates at 6.5e11 wave-insts/s on the
+                        # (v_pk_* 5.4, v_mad_u64_u32 4.2, v_fma_f32 3.2 cycles) saturates at 6.4e11 wave-insts/s on the
                         # chip (524 288 chains = 8 waves/SIMD); one wave per SIMD -- the 65 536-chain shape -- cannot
                         # issue faster than one instruction per ~4.7 cycles.
                         "issue_peak_wave_insts_per_s": 1024 * 1.0e9,
                         "issue_frac": wave_insts_per_s / (1024 * 1.0e9),
-                        "mix_saturated_wave_insts_per_s": 6.5e11,
-                        "mix_frac": wave_insts_per_s / 6.5e11}
+                        "mix_saturated_wave_insts_per_s": 6.4e11,
+                        "mix_frac": wave_insts_per_s / 6.4e11}
         except (OSError, KeyError, ValueError):
             pass
         out = {
