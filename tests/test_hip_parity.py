@@ -639,12 +639,14 @@ def test_fast_index_equals_ieee_index(hip, eps, N, lanes):
     assert int(cf.n_moves.sum()) > 0
 
 
-@pytest.mark.parametrize("y_obs,n", [((1e-3, 2.0), 3000), ((0.0, 0.0), 3000), ((1.5, 1.5), 200000)])
-def test_unit_gaussian_variant_and_its_fallback(hip, oracle, y_obs, n):
+@pytest.mark.parametrize("y_obs,n,eps", [((1e-3, 2.0), 3000, 0.2), ((0.0, 0.0), 3000, 0.2), ((1.5, 1.5), 200000, 0.2),
+                                         ((1.5, 1.5), 3000, 3e6), ((1.5, 1.5), 3000, 0.7311), ((1.5, 1.5), 3000, 1.9999999)])
+def test_unit_gaussian_variant_and_its_fallback(hip, oracle, y_obs, n, eps):
     """The branch-free unit-Gaussian kernel variant (lean square root, no +0 log-scale terms) needs every
-    |y_obs_j| >= 2^-6; other observations take the generic kernels.  Both against the oracle, bit for bit -- the large
-    case (more than two waves per SIMD) also exercises the default-schedule object."""
-    cfg = dict(epsilon=0.2, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    |y_obs_j| >= 2^-6 and a kernel scale in [2^-20, 2^20] whose reciprocal division the host verified; other
+    configurations take the generic kernels.  All against the oracle (IEEE division, full sqrt), bit for bit -- the
+    large case (more than two waves per SIMD) also exercises the default-schedule object."""
+    cfg = dict(epsilon=eps, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
     model, local, glob = descriptors(cfg)
     for j in range(2):
         model.y_obs[j] = y_obs[j]
