@@ -61,7 +61,7 @@ struct NfArgs {
     float* log_q;                 // [n]
     int64_t n_rows, row0;
     uint32_t seed_lo, seed_hi;
-    int32_t rows_per_wg;          // multiple of 64
+    int32_t rows_per_wg;          // multiple of 64 (pairs), of 32 in tile mode
 };
 
 // (shift, log_s) of one coupling for this lane's two rows (one in tile a, one in tile b), conditioner inputs z0a / z0b;
@@ -129,25 +129,80 @@ __device__ __forceinline__ void coupling_params2(const float* __restrict__ lds, 
     log_s_b = ((half ? qb1 : pb1) + (half ? pb1 : qb1)) + b31;
 }
 
+// One row tile per wavefront: the form for small inputs (at most one tile per CU), where the launch is a latency chain
+// and half the MFMAs per coupling beat operand reuse.  Same arithmetic per row as coupling_params2.
+__device__ __forceinline__ void coupling_params(const float* __restrict__ lds, float z0, int lane, float& shift, float& log_s)
+{
+    const int half = lane >> 5, col = lane & 31;
+    f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        acc0[r] = lds[NF_V4_OFF + 4 * i];
+        acc1[r] = lds[NF_V4_OFF + 4 * (i + 32)];
+        acc2[r] = lds[NF_V4_OFF + 4 * (i + 64)];
+        acc3[r] = lds[NF_V4_OFF + 4 * (i + 96)];
+    }
+    const float* w1 = lds + NF_W1_OFF + half;
+    const float* b1 = lds + NF_B1_OFF + half;
+    const float* wt = lds + NF_W2_OFF + half * NF_H + col;                // W2^T[2s + half][32t + col]
+#pragma unroll 8
+    for (int s = 0; s < 64; ++s) {
+        const float h1 = __builtin_fmaxf(__builtin_fmaf(w1[2 * s], z0, b1[2 * s]), 0.0f);
+        const float* row = wt + 2 * s * NF_H;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[0], h1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[32], h1, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[64], h1, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[96], h1, acc3, 0, 0, 0);
+    }
+    float p0 = 0.0f, p1 = 0.0f;
+    auto epilogue = [&](const f32x16& acc, int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float2 v = *reinterpret_cast<const float2*>(lds + NF_V4_OFF + 4 * i + 1);     // (W3[0][i], W3[1][i])
+            const float h2 = __builtin_fmaxf(acc[r], 0.0f);
+            p0 = __builtin_fmaf(v.x, h2, p0);
+            p1 = __builtin_fmaf(v.y, h2, p1);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // keep the next tile's LDS reads from being hoisted above (VGPR pressure)
+    };
+    epilogue(acc0, 0);
+    epilogue(acc1, 1);
+    epilogue(acc2, 2);
+    epilogue(acc3, 3);
+    // partial sums of the two halves of the row: lane l <-> l + 32
+    const float q0 = __shfl_xor(p0, 32, 64), q1 = __shfl_xor(p1, 32, 64);
+    const float lo0 = half ? q0 : p0, hi0 = half ? p0 : q0;
+    const float lo1 = half ? q1 : p1, hi1 = half ? p1 : q1;
+    shift = (lo0 + hi0) + lds[NF_B3_OFF + 0];
+    log_s = (lo1 + hi1) + lds[NF_B3_OFF + 1];
+}
+
 template <bool INVERSE, int NP>
 __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31;
+    constexpr bool TILE_MODE = (NP == 0);                              // one 32-row tile per wave (small inputs)
+    constexpr int NT = TILE_MODE ? 1 : 2 * NP, NPAIR = TILE_MODE ? 1 : NP;
     const int n_pairs = a.rows_per_wg / 64;                            // 64-row pairs of 32-row tiles in this workgroup
     const int64_t wg_row0 = (int64_t)blockIdx.x * a.rows_per_wg;
+    auto tile_row = [&](int q) -> int64_t {
+        if (TILE_MODE) return wg_row0 + (int64_t)wave * 32 + col;
+        return wg_row0 + (int64_t)(wave + (q >> 1) * NF_WAVES) * 64 + (q & 1) * 32 + col;
+    };
 
     // Pair p of the workgroup (rows wg_row0 + 64p .. +63) belongs to wave p % NF_WAVES, slot p / NF_WAVES: when the
     // pairs do not divide evenly the extra ones land on waves 0.., i.e. on different SIMDs.  Tile 2q is the first
     // 32 rows of the wave's q-th pair, tile 2q+1 the second.
-    float z0[2 * NP], z1[2 * NP], lq[2 * NP];
-    bool valid[2 * NP], active[NP];
+    float z0[NT], z1[NT], lq[NT];
+    bool valid[NT], active[NPAIR];
 #pragma unroll
-    for (int q = 0; q < 2 * NP; ++q) {
-        const int pair = wave + (q >> 1) * NF_WAVES;
-        active[q >> 1] = pair < n_pairs;                               // wave-uniform
-        const int64_t row = wg_row0 + (int64_t)pair * 64 + (q & 1) * 32 + col;
+    for (int q = 0; q < NT; ++q) {
+        active[q >> 1] = TILE_MODE ? (wave * 32 < a.rows_per_wg) : (wave + (q >> 1) * NF_WAVES < n_pairs);   // wave-uniform
+        const int64_t row = tile_row(q);
         valid[q] = active[q >> 1] && row < a.n_rows;
         const int64_t rr = valid[q] ? row : a.n_rows - 1;
         if (INVERSE) {
@@ -193,22 +248,30 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
             }
         };
         // inverse: flows reversed -> Permute^-1 (the swap again) first, so the conditioner input is z1
+        if constexpr (TILE_MODE) {
+            if (active[0]) {
+                const float ca = INVERSE ? z1[0] : z0[0], ta = z0[0];
+                float sa, la;
+                coupling_params(lds, ca, lane, sa, la);
+                apply(0, sa, la, ca, ta);
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < 2 * NP; q += 2) {
-            if (!active[q >> 1]) continue;
-            const float ca = INVERSE ? z1[q] : z0[q], cb = INVERSE ? z1[q + 1] : z0[q + 1];
-            const float ta = z0[q], tb = z0[q + 1];
-            float sa, la, sb, lb;
-            coupling_params2(lds, ca, cb, lane, sa, la, sb, lb);
-            apply(q, sa, la, ca, ta);
-            apply(q + 1, sb, lb, cb, tb);
+            for (int q = 0; q < NT; q += 2) {
+                if (!active[q >> 1]) continue;
+                const float ca = INVERSE ? z1[q] : z0[q], cb = INVERSE ? z1[q + 1] : z0[q + 1];
+                const float ta = z0[q], tb = z0[q + 1];
+                float sa, la, sb, lb;
+                coupling_params2(lds, ca, cb, lane, sa, la, sb, lb);
+                apply(q, sa, la, ca, ta);
+                apply(q + 1, sb, lb, cb, tb);
+            }
         }
     }
 
 #pragma unroll
-    for (int q = 0; q < 2 * NP; ++q) {
-        const int pair = wave + (q >> 1) * NF_WAVES;
-        const int64_t row = wg_row0 + (int64_t)pair * 64 + (q & 1) * 32 + col;
+    for (int q = 0; q < NT; ++q) {
+        const int64_t row = tile_row(q);
         if (valid[q] && lane < 32) {
             if (INVERSE) {
                 // + q0.log_prob(z): C - sum(log_scale + 0.5 ((z - loc)/exp(log_scale))^2)
@@ -282,6 +345,10 @@ static int nf_launch_np(NfArgs a, int rows_per_wg, hipStream_t s)
 template <bool INV>
 static int nf_launch(const NfArgs& a, hipStream_t s)
 {
+    const int64_t tiles = (a.n_rows + 31) / 32;
+    // up to one tile per CU (8192 rows) the launch is a latency chain of couplings: one tile per workgroup halves it
+    // against one pair per workgroup.  (With more tiles than CUs, pairs win again: 65 536 rows measured 77 vs 65 TFLOP/s.)
+    if (tiles <= (int64_t)NF_CUS) return nf_launch_np<INV, 0>(a, 32, s);
     const int64_t pairs = (a.n_rows + 63) / 64;
     int64_t pairs_per_wg = (pairs + NF_CUS - 1) / NF_CUS;
     const int64_t cap = (int64_t)NF_WAVES * NF_MAX_PAIRS;
