@@ -112,8 +112,10 @@ GLABC_DEV double model_log_kernel_f64(const StepArgs<D>& a, const double (&y)[D]
     return (-0.5 * 1.0 * GLABC_LOG_2PI) - ((double)a.kern_log_scale + 0.5 * (e * e));
 }
 
-// discrepancy, Mixture.py:33-36, float32
-template <int D>
+// discrepancy, Mixture.py:33-36, float32.  LEAN: the launcher knows every |y_obs_j| >= 2^-6 (StepArgs::y_obs_away), so
+// the sum of squares is 0 or >= 2^-62 and the square root without the rescaling of tiny arguments is the correctly
+// rounded one (glabc_numerics.h) -- 8 instructions less, 400 times per gradient
+template <int D, bool LEAN = false>
 GLABC_DEV float model_discrepancy(const StepArgs<D>& a, const float (&y)[D])
 {
     float t[D];
@@ -122,7 +124,8 @@ GLABC_DEV float model_discrepancy(const StepArgs<D>& a, const float (&y)[D])
         float d = y[j] - a.y_obs[j];
         t[j] = d * d;
     }
-    return __builtin_sqrtf(aten_rowsum<D>(t));      // (a run-time switch to the lean square root measured slower here)
+    const float ss = aten_rowsum<D>(t);
+    return LEAN ? glabc_sqrtf_normal(ss) : __builtin_sqrtf(ss);
 }
 
 template <int D>
@@ -173,7 +176,7 @@ GLABC_DEV double shfl_f64(double v, int src)
 // shifted discrepancies in exact fixed point (glabc_fxsum: integer sums, so the split cannot change a bit), merge
 // the partial sums with xor-shuffles and all finish the statistics; the result goes back to the owning lane.
 // srcmap: 64 ints of LDS (one wavefront per workgroup).
-template <int D>
+template <int D, bool LEAN = false>
 GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step, int g, bool need, const float (&theta)[D],
                              double (&grad)[D], int* srcmap)
 {
@@ -213,7 +216,7 @@ GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step
         }
         model_simulate<D>(a, tp, zero, y0p);                            // centres: the noise-free discrepancies
         model_simulate<D>(a, tm, zero, y0m);
-        const double c_p = (double)model_discrepancy<D>(a, y0p), c_m = (double)model_discrepancy<D>(a, y0m);
+        const double c_p = (double)model_discrepancy<D, LEAN>(a, y0p), c_m = (double)model_discrepancy<D, LEAN>(a, y0m);
         glabc_fxsum ap, am;
         ap.s1 = am.s1 = 0;
         ap.s2_lo = ap.s2_hi = am.s2_lo = am.s2_hi = 0;
@@ -222,8 +225,8 @@ GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step
             float yp[D], ym[D];
             model_simulate<D>(a, tp, eps, yp);                          // GLMALA.py:78
             model_simulate<D>(a, tm, eps, ym);                          // GLMALA.py:82 (same noise)
-            glabc_fx_add(&ap, glabc_fx_quantize((double)model_discrepancy<D>(a, yp) - c_p));
-            glabc_fx_add(&am, glabc_fx_quantize((double)model_discrepancy<D>(a, ym) - c_m));
+            glabc_fx_add(&ap, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, yp) - c_p));
+            glabc_fx_add(&am, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, ym) - c_m));
         };
         if constexpr (D == 2) {
             // a Philox block holds the four normals of TWO consecutive simulations: lanes walk blocks, not simulations
@@ -305,7 +308,7 @@ GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step
 
 // the MALA local move, GLMALA.py:182-200.  Every lane calls it (the gradients are wave-cooperative);
 // `is_local` marks the chains that take the move this iteration.
-template <int D>
+template <int D, bool LEAN = false>
 GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, bool is_local, float u_accept,
                          const float (&zn)[2 * D], MalaChain<D>& c, int* srcmap)
 {
@@ -314,7 +317,7 @@ GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, bo
 #pragma unroll
     for (int j = 0; j < D; ++j) thf[j] = (float)c.theta[j];
     const bool init = is_local && !(c.flags & GLABC_FLAG_HAS_GRAD);                          // :183-184
-    coop_gradient<D>(m, rng, step, 0, init, thf, c.grad, srcmap);
+    coop_gradient<D, LEAN>(m, rng, step, 0, init, thf, c.grad, srcmap);
     if (init) c.flags |= GLABC_FLAG_HAS_GRAD;
     // Local_proposal_forward, :25-44
     float t[D];
@@ -336,7 +339,7 @@ GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, bo
         thf[j] = (float)x[j];                                                                // :62
         gprop[j] = 0.0;
     }
-    coop_gradient<D>(m, rng, step, 1, is_local, thf, gprop, srcmap);                         // :187
+    coop_gradient<D, LEAN>(m, rng, step, 1, is_local, thf, gprop, srcmap);                         // :187
     if (!is_local) return false;
     double y[D];
 #pragma unroll
@@ -468,7 +471,7 @@ GLABC_DEV bool mala_isir_move(const MalaArgs<D>& m, const Rng& rng, uint32_t ste
     return moved;
 }
 
-template <int D, int N>
+template <int D, int N, bool LEAN>
 __global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
 {
     const StepArgs<D>& a = m.s;
@@ -528,7 +531,7 @@ __global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
                 zn[j] = e[j];
                 zn[D + j] = s[j];
             }
-            const bool mv = mala_move<D>(m, rng, step, !is_global && valid, glabc_uniform_f32(h.v[1]), zn, c, srcmap);
+            const bool mv = mala_move<D, LEAN>(m, rng, step, !is_global && valid, glabc_uniform_f32(h.v[1]), zn, c, srcmap);
             moved = is_global ? moved : mv;
         }
         c.n_moves += moved ? 1u : 0u;

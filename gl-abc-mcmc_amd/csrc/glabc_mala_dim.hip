@@ -12,7 +12,10 @@ template <int D, int N>
 static int launch_mala(const MalaArgs<D>& m, hipStream_t s)
 {
     const unsigned grid = (unsigned)((m.s.n_chains + 63) / 64);
-    hipLaunchKernelGGL((glmala_kernel<D, N>), dim3(grid), dim3(64), 0, s, m);
+    if (m.s.y_obs_away)
+        hipLaunchKernelGGL((glmala_kernel<D, N, true>), dim3(grid), dim3(64), 0, s, m);
+    else
+        hipLaunchKernelGGL((glmala_kernel<D, N, false>), dim3(grid), dim3(64), 0, s, m);
     return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
 }
 
