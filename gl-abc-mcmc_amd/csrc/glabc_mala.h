@@ -217,16 +217,14 @@ GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step
         model_simulate<D>(a, tp, zero, y0p);                            // centres: the noise-free discrepancies
         model_simulate<D>(a, tm, zero, y0m);
         const double c_p = (double)model_discrepancy<D, LEAN>(a, y0p), c_m = (double)model_discrepancy<D, LEAN>(a, y0m);
-        glabc_fxsum ap, am;
-        ap.s1 = am.s1 = 0;
-        ap.s2_lo = ap.s2_hi = am.s2_lo = am.s2_hi = 0;
+        glabc_fxsplit ap = {0, 0, 0, 0}, am = {0, 0, 0, 0};             // exact sums, split squares (glabc_numerics.h)
         // one simulation of coordinate k with noise index s
         auto one_sim = [&](const float (&eps)[D]) {
             float yp[D], ym[D];
             model_simulate<D>(a, tp, eps, yp);                          // GLMALA.py:78
             model_simulate<D>(a, tm, eps, ym);                          // GLMALA.py:82 (same noise)
-            glabc_fx_add(&ap, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, yp) - c_p));
-            glabc_fx_add(&am, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, ym) - c_m));
+            glabc_fxs_add(&ap, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, yp) - c_p));
+            glabc_fxs_add(&am, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, ym) - c_m));
         };
         if constexpr (D == 2) {
             // a Philox block holds the four normals of TWO consecutive simulations: lanes walk blocks, not simulations
@@ -270,18 +268,21 @@ GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step
             }
         }
         for (int mm = G >> 1; mm >= 1; mm >>= 1) {                      // merge the group's partial sums (exact integers)
-            glabc_fxsum bp, bm;
+            glabc_fxsplit bp, bm;
             bp.s1 = (int64_t)shfl_xor_u64((uint64_t)ap.s1, mm);
-            bp.s2_lo = shfl_xor_u64(ap.s2_lo, mm);
-            bp.s2_hi = shfl_xor_u64(ap.s2_hi, mm);
+            bp.a = shfl_xor_u64(ap.a, mm);
+            bp.b = (int64_t)shfl_xor_u64((uint64_t)ap.b, mm);
+            bp.c = shfl_xor_u64(ap.c, mm);
             bm.s1 = (int64_t)shfl_xor_u64((uint64_t)am.s1, mm);
-            bm.s2_lo = shfl_xor_u64(am.s2_lo, mm);
-            bm.s2_hi = shfl_xor_u64(am.s2_hi, mm);
-            glabc_fx_merge(&ap, &bp);
-            glabc_fx_merge(&am, &bm);
+            bm.a = shfl_xor_u64(am.a, mm);
+            bm.b = (int64_t)shfl_xor_u64((uint64_t)am.b, mm);
+            bm.c = shfl_xor_u64(am.c, mm);
+            glabc_fxs_merge(&ap, &bp);
+            glabc_fxs_merge(&am, &bm);
         }
+        const glabc_fxsum fp = glabc_fxs_finish(&ap), fm = glabc_fxs_finish(&am);
         const double nd = (double)num;
-        const double s1p = glabc_fx_sum1(&ap), s2p = glabc_fx_sum2(&ap), s1m = glabc_fx_sum1(&am), s2m = glabc_fx_sum2(&am);
+        const double s1p = glabc_fx_sum1(&fp), s2p = glabc_fx_sum2(&fp), s1m = glabc_fx_sum1(&fm), s2m = glabc_fx_sum2(&fm);
         const double mu_p = c_p + s1p / nd, mu_m = c_m + s1m / nd;                           // GLMALA.py:86-87
         const double var_p = (s2p - (s1p * s1p) / nd) / (nd - 1.0), var_m = (s2m - (s1m * s1m) / nd) / (nd - 1.0);   // :88-89
         const double lp = (-0.5 * glabc_log(var_p + m.eps_sq)) - ((0.5 * (mu_p * mu_p)) / (var_p + m.eps_sq));   // :90-91

@@ -332,6 +332,54 @@ GLABC_HD void glabc_fx_merge(glabc_fxsum* a, const glabc_fxsum* b)
     a->s2_hi = a->s2_hi + b->s2_hi + (a->s2_lo < old ? 1u : 0u);
 }
 
+/* The same sums with the square split in three 64-bit accumulators -- q = h 2^24 + l, q^2 = h^2 2^48 + h l 2^25 + l^2 --
+ * so that one term costs three 32x32->64 multiply-accumulates instead of a 128-bit square: the form the gfx950 gradient
+ * loop uses.  Exact for |q| < 2^47 (|d| < 128) and up to 65 536 terms, like glabc_fxsum; glabc_fxs_finish returns the
+ * identical glabc_fxsum (integers: nothing is rounded), which tests/test_numerics.py checks on random streams. */
+typedef struct { int64_t s1; uint64_t a; int64_t b; uint64_t c; } glabc_fxsplit;
+
+GLABC_HD void glabc_fxs_add(glabc_fxsplit* x, int64_t q)
+{
+    const int32_t h = (int32_t)(q >> 24);                  /* floor split: l is the unsigned low part */
+    uint32_t l = (uint32_t)q & 0xffffffu;
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* ROCm 7.2's gfx950 backend turns the square of a value it knows to be 24 bits wide into a 24-bit-multiply node, drops
+     * the mask as implied by that node, and then selects the full 32-bit v_mad_u64_u32 on the UNMASKED register
+     * (tools/ubench/fx_check.hip shows it).  Hiding the value's width keeps the mask. */
+    __asm__("" : "+v"(l));
+#endif
+    x->s1 += q;
+    x->a += (uint64_t)((int64_t)h * (int64_t)h);
+    x->b += (int64_t)h * (int64_t)l;
+    x->c += (uint64_t)l * (uint64_t)l;
+}
+
+GLABC_HD void glabc_fxs_merge(glabc_fxsplit* x, const glabc_fxsplit* y)
+{
+    x->s1 += y->s1;
+    x->a += y->a;
+    x->b += y->b;
+    x->c += y->c;
+}
+
+GLABC_HD glabc_fxsum glabc_fxs_finish(const glabc_fxsplit* x)
+{
+    glabc_fxsum r;
+    r.s1 = x->s1;
+    /* 128-bit  a 2^48 + b 2^25 + c  (b signed; the total is a sum of squares, so non-negative) */
+    uint64_t lo = x->c, hi = 0;
+    const uint64_t a_lo = x->a << 48, a_hi = x->a >> 16;
+    lo += a_lo;
+    hi += a_hi + (lo < a_lo ? 1u : 0u);
+    const uint64_t b_lo = (uint64_t)x->b << 25, b_hi = (uint64_t)(x->b >> 39);      /* sign-extended high part */
+    const uint64_t old = lo;
+    lo += b_lo;
+    hi += b_hi + (lo < old ? 1u : 0u);
+    r.s2_lo = lo;
+    r.s2_hi = hi;
+    return r;
+}
+
 /* sum(d) and sum(d^2) as doubles */
 GLABC_HD double glabc_fx_sum1(const glabc_fxsum* a) { return (double)a->s1 * 0x1p-40; }
 GLABC_HD double glabc_fx_sum2(const glabc_fxsum* a)

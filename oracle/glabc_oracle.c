@@ -1430,6 +1430,20 @@ ORACLE_API void oracle_expf_v(const float* x, int64_t n, float* out)
     for (int64_t i = 0; i < n; ++i) out[i] = glabc_expf(x[i]);
 }
 
+/* test hook: both fixed-point accumulators over the same stream of quantised terms -> (s1, s2_lo, s2_hi) twice */
+ORACLE_API void oracle_fx_both(const int64_t* q, int64_t n, uint64_t* out6)
+{
+    glabc_fxsum a = {0, 0, 0};
+    glabc_fxsplit b = {0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        glabc_fx_add(&a, q[i]);
+        glabc_fxs_add(&b, q[i]);
+    }
+    glabc_fxsum c = glabc_fxs_finish(&b);
+    out6[0] = (uint64_t)a.s1; out6[1] = a.s2_lo; out6[2] = a.s2_hi;
+    out6[3] = (uint64_t)c.s1; out6[4] = c.s2_lo; out6[5] = c.s2_hi;
+}
+
 ORACLE_API void oracle_expf_b_v(const float* x, int64_t n, float* out)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = glabc_expf_b(x[i]);

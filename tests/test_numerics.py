@@ -115,3 +115,20 @@ def test_expf_select_form_equals_early_return_form(oracle):
     nan = np.isnan(a)
     assert np.array_equal(nan, np.isnan(b)) and np.array_equal(nan, np.isnan(x))
     assert np.array_equal(a[~nan].view(np.uint32), b[~nan].view(np.uint32))
+
+
+def test_split_fixed_point_accumulator_equals_the_128_bit_one(oracle):
+    """glabc_fxsplit (three 64-bit multiply-accumulates per term, the gradient loop's form) and glabc_fxsum (128-bit square)
+    give the same integers: random streams up to the documented limits (|q| < 2^47, 65 536 terms), all-extreme streams."""
+    rng = np.random.default_rng(1)
+    streams = [rng.integers(-(1 << 47) + 1, 1 << 47, 65536), np.full(65536, (1 << 47) - 1), np.full(65536, -(1 << 47) + 1),
+               rng.integers(-(1 << 20), 1 << 20, 1000), np.array([0, 1, -1, (1 << 24) - 1, -(1 << 24), 1 << 24, -(1 << 24) - 1]),
+               (rng.standard_normal(400) * 0.22 * 2.0 ** 40).astype(np.int64)]
+    for q in streams:
+        q = np.ascontiguousarray(q, np.int64)
+        out = np.zeros(6, np.uint64)
+        oracle.oracle_fx_both(q.ctypes.data, q.size, out.ctypes.data)
+        assert np.array_equal(out[:3], out[3:]), (out, q[:4])
+        # and both equal the exact integer sums
+        s2 = sum(int(v) * int(v) for v in q)
+        assert int(out[1]) + (int(out[2]) << 64) == s2 and np.int64(out[0]) == q.sum()
