@@ -1430,6 +1430,11 @@ ORACLE_API void oracle_expf_v(const float* x, int64_t n, float* out)
     for (int64_t i = 0; i < n; ++i) out[i] = glabc_expf(x[i]);
 }
 
+ORACLE_API void oracle_fx_quantize_v(const double* d, int64_t n, int64_t* out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = glabc_fx_quantize(d[i]);
+}
+
 /* test hook: both fixed-point accumulators over the same stream of quantised terms -> (s1, s2_lo, s2_hi) twice */
 ORACLE_API void oracle_fx_both(const int64_t* q, int64_t n, uint64_t* out6)
 {

@@ -52,6 +52,7 @@ _SIG = {
     "oracle_esjd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "oracle_philox4x32_10": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "oracle_expf_v": (None, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "oracle_fx_quantize_v": (None, [C.c_void_p, C.c_int64, C.c_void_p]),
     "oracle_fx_both": (None, [C.c_void_p, C.c_int64, C.c_void_p]),
     "oracle_expf_b_v": (None, [C.c_void_p, C.c_int64, C.c_void_p]),
     "oracle_logf_v": (None, [C.c_void_p, C.c_int64, C.c_void_p]),

@@ -132,3 +132,15 @@ def test_split_fixed_point_accumulator_equals_the_128_bit_one(oracle):
         # and both equal the exact integer sums
         s2 = sum(int(v) * int(v) for v in q)
         assert int(out[1]) + (int(out[2]) << 64) == s2 and np.int64(out[0]) == q.sum()
+
+
+def test_fx_quantize_is_rint_times_2_40(oracle):
+    """glabc_fx_quantize's add-the-magic-constant form equals (int64) rint(d * 2^40) -- ties to even included -- on its
+    domain |d| < 2^11 (the sampler stays below 2^7)."""
+    rng = np.random.default_rng(2)
+    d = np.concatenate([rng.standard_normal(1_000_000) * 0.3, rng.uniform(-2047, 2047, 1_000_000), rng.uniform(0, 1, 200_000),
+                        (rng.integers(-(1 << 50), 1 << 50, 200_000) + 0.5) * 2.0 ** -40,        # exact ties
+                        np.array([0.0, -0.0, 2.0 ** -41, -2.0 ** -41, 3 * 2.0 ** -41, 1.0, -1.0, 2047.999, -2047.999])])
+    out = np.empty(d.size, np.int64)
+    oracle.oracle_fx_quantize_v(d.ctypes.data, d.size, out.ctypes.data)
+    assert np.array_equal(out, np.rint(d * 2.0 ** 40).astype(np.int64))
