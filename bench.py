@@ -308,8 +308,12 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_chain_step": algo_bytes / (n * K),
                          "valu": valu,
-                         "note": "the step is VALU-issue-bound, not HBM-bound: ~1260 vector instructions per chain-"
-                                 "step against 8 algorithmic bytes (Philox + Box-Muller + densities); see DESIGN.md"},
+                         "note": {"glmcmc": "the step is VALU-issue-bound, not HBM-bound: ~1260 vector instructions per chain-"
+                                            "step against 8 algorithmic bytes (Philox + Box-Muller + densities); see DESIGN.md",
+                                  "globalmcmc": "VALU-bound like the GLMCMC step (one candidate per iteration); see DESIGN.md 4.1",
+                                  "glmala": "VALU-bound: a MALA move costs 400 simulations for its finite-difference gradient "
+                                            "(~14 000 vector instructions per chain-step on average); see DESIGN.md 4.1b",
+                                  "gk": "VALU-bound: 8 g-and-k variates (exp, tanh, pow) + a sort per candidate; see DESIGN.md"}[args.workload]},
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "glmcmc":
             out["cpu_baseline"] = cpu_baseline()
