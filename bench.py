@@ -134,6 +134,42 @@ def bench_nf(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_kde(args):
+    """KernelDensity.log_prob (kernel_density.py:96-128), the dense (points x centres) logsumexp of
+    AGLMCMC's adaptive proposal: 524 288 evaluation points against 8192 weighted centres in d = 2 per step."""
+    from glabcmcmc_amd import KernelDensity
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    S, P = 8192, 8 * args.chains
+    kde = KernelDensity(device="cuda", seed=1).fit(torch.randn(S, 2), torch.rand(S))
+    pts = torch.randn(2, P, device="cuda")
+    for _ in range(args.warmup):
+        kde.log_prob_soa(pts)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        out = kde.log_prob_soa(pts)
+        b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    algo_bytes = 4.0 * (3 * P + 3 * S + P)                      # points in, centres + log-weights in, densities out
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    print(json.dumps({"metric": "KDE log-density pair evaluations/sec (points x centres), d = 2", "value": float(S) * P * args.steps / elapsed,
+                      "unit": "pair-evaluations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "KernelDensity.log_prob, %d points x %d centres, d=2 (AGLMCMC's adaptive proposal)" % (P, S)},
+                      "finite": bool(torch.isfinite(out).all()),
+                      "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                   "traffic": None, "kernel": "kde_log_prob_kernel<2>", "kernel_ms": kernel_ms,
+                                   "algorithmic_bytes_per_launch": algo_bytes,
+                                   "note": "dense O(points x centres) arithmetic on O(points + centres) bytes: VALU-bound by "
+                                           "construction (~60 vector instructions per pair over two passes); see DESIGN.md 4.3"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,12 +184,14 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the multi-rank control flow on ONE GPU: every rank uses cuda:0 and the collectives "
                          "run on gloo with CPU copies (numbers are meaningless; RCCL needs one GPU per rank)")
-    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk"],
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
     if args.workload == "nf":
         return bench_nf(args)
+    if args.workload == "kde":
+        return bench_kde(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
