@@ -661,3 +661,24 @@ def test_unit_gaussian_variant_and_its_fallback(hip, oracle, y_obs, n, eps):
     assert np.array_equal(bits(hist), bits(hh))
     assert_same_state(chains, hc, True)
     assert hc.n_moves.sum() > 0
+
+
+def test_sharded_example_is_invariant_to_the_number_of_ranks(hip):
+    """examples/Mixture_sharded.py with 1 rank and with 2 ranks (gloo, both on this GPU): the same chains, hence the same
+    pooled statistics to the last bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG_PARENT
+    env = dict(os.environ, PYTHONPATH=PKG_PARENT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    args = ["-m", "glabcmcmc_amd.examples.Mixture_sharded", "--chains", "6000", "--iters", "150", "--backend", "gloo", "--one-gpu"]
+    one = subprocess.run([sys.executable] + args, env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29541"] + args, env=env, capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads(one.stdout.strip().split("\n")[-1])
+    b = json.loads([l for l in two.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert (a["ranks"], b["ranks"]) == (1, 2) and a["chains"] == b["chains"] == 6000
+    assert a["esjd_checksum"] == b["esjd_checksum"] and a["mean_theta_sq"] == b["mean_theta_sq"]
