@@ -682,3 +682,27 @@ def test_sharded_example_is_invariant_to_the_number_of_ranks(hip):
     b = json.loads([l for l in two.stdout.strip().split("\n") if l.startswith("{")][-1])
     assert (a["ranks"], b["ranks"]) == (1, 2) and a["chains"] == b["chains"] == 6000
     assert a["esjd_checksum"] == b["esjd_checksum"] and a["mean_theta_sq"] == b["mean_theta_sq"]
+
+
+def test_streamed_history_equals_the_in_memory_one(hip, tmp_path):
+    """streaming.stream_history: history blocks leave over a copy stream + writer thread while the next
+    block is computed; the .npy file holds exactly the rows of one in-memory run, for block sizes that do and do not
+    divide the run."""
+    from glabcmcmc_amd import engine, streaming
+    cfg = dict(epsilon=0.3, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(3)
+    n, T, seed = 4096, 230, 17
+    theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+    y0 = np.abs(theta0).astype(np.float32)
+    full, cfull, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, seed, 0.8, 5)
+    dev = torch.device("cuda", 0)
+    for block in (50, 64, 1000):
+        chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev)
+        engine.init_weights(model, glob, chains)
+        path = str(tmp_path / ("hist_%d.npy" % block))
+        shape = streaming.stream_history("glabc_glmcmc_steps", model, local, glob, chains, T, seed, 0.8, 5, path, block=block)
+        assert tuple(shape) == (T, 2, n)
+        got = np.load(path)
+        assert np.array_equal(bits(got), bits(full)), block
+        assert np.array_equal(bits(chains.theta.cpu().numpy()), bits(cfull.theta.cpu().numpy()))
