@@ -19,7 +19,7 @@ from .AGLMCMC import AGLMCMC
 from .GLMCMC_NFs import GLMCMC_NF
 from .ESJD import esjd
 from .kernel_density import KernelDensity
-from . import _capi, distribution, engine, flows
+from . import _capi, checkpoint, distribution, engine, flows, parallel, streaming
 
 __all__ = ["GlobalMCMC", "MCMCRunner", "Uniform", "Gamma", "DiagGaussian", "GaussianMixture", "GLMALA", "GLMCMC",
            "AGLMCMC", "GLMCMC_NF", "esjd", "KernelDensity", "distribution", "engine"]
