@@ -84,6 +84,7 @@ struct StepArgs {
     uint32_t seed_lo, seed_hi, step0;
     int32_t n_steps;
     float gf;
+    const float* gf_chain;       // NULL or [n_chains]: per-chain global_frequency (glabc_run.global_frequency_per_chain)
     float* history;
     int64_t hist_stride;
     double* sum_theta;
@@ -348,6 +349,7 @@ struct Chain {
     float log_w;      // log_weight_old, GLMCMC.py:53-55 -- stale after an accepted local move until the next global step
     float lw_cur;     // (prior + kern) - q of the CURRENT state: what GLMCMC.py:60-64 will assign to log_weight_old (cache)
     float w_cur;      // exp(lw_cur), NaN -> 0: the current state's iSIR weight, GLMCMC.py:75-81 (cache)
+    float gf;         // this chain's global_frequency
     uint32_t flags;
     uint32_t n_moves;
 };
@@ -401,7 +403,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         // GLMCMC.py:98: log(u).  A Philox uniform is k 2^-24 -- zero or a normal float -- so the special cases of
         // glabc_logf reduce to one select (same bits); a tape may hold anything
         log_u = TAPE ? glabc_logf(ua) : ((ua == 0.0f) ? -__builtin_inff() : glabc_logf_normal(ua));
-        is_global = ub < a.gf;                                                // GLMCMC.py:59 / GlobalMCMC.py:39
+        is_global = ub < c.gf;                                                // GLMCMC.py:59 / GlobalMCMC.py:39
         if (ALGO == ALGO_GLMCMC && is_global) {
             if (c.flags & GLABC_FLAG_LOCAL) c.log_w = c.lw_cur;                   // GLMCMC.py:60-64
             c.flags &= ~GLABC_FLAG_LOCAL;                                         // GLMCMC.py:65

@@ -580,6 +580,7 @@ static StepArgs<D, YD> pack_args(const glabc_model* m, const glabc_dist* local, 
         a.n_steps = r->n_steps;
         a.exact_index = (r->debug_flags & GLABC_DEBUG_EXACT_INDEX) ? 1 : 0;
         a.gf = r->global_frequency;
+        a.gf_chain = r->global_frequency_per_chain;
         a.history = r->history;
         a.hist_stride = r->hist_stride;
         if (r->moments) {
@@ -729,6 +730,7 @@ __attribute__((visibility("default"))) int glabc_glmala_steps(const glabc_model*
     if (rc) return rc;
     if (r->n_steps < 0 || r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH) return GLABC_ERR_ARG;
     if (!(r->global_frequency >= 0.0f) && !(r->global_frequency < 0.0f)) return GLABC_ERR_ARG;
+    if (r->global_frequency_per_chain) return GLABC_ERR_ARG;        // GLMCMC / GlobalMCMC only
     if (mala->num_grad < 2 || mala->num_grad > (1 << 16) || !(mala->tau > 0.0) || !std::isfinite(mala->tau) ||
         !std::isfinite(mala->tau_sq) || !std::isfinite(mala->eps_sq) || !(mala->eps_sq >= 0.0))
         return GLABC_ERR_ARG;
@@ -896,7 +898,7 @@ __attribute__((visibility("default"))) int glabc_glmcmc_nf_step(const glabc_mode
     if (c->n_chains < 0 || c->stride < c->n_chains || c->chain0 < 0 || pool->step_size < 1) return GLABC_ERR_ARG;
     if (r->n_steps != 1 || r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH) return GLABC_ERR_ARG;
     if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
-    if (r->tape || r->moments) return GLABC_ERR_ARG;
+    if (r->tape || r->moments || r->global_frequency_per_chain) return GLABC_ERR_ARG;
     if (c->n_chains == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;
 #define GLABC_NFSTEP(d)                                                       \

@@ -132,13 +132,14 @@ class Moments:
 
 
 def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0, seed, global_frequency, batch_size,
-              history=None, moments=None, steps_per_launch=None, lanes_per_chain=0, debug_flags=0):
+              history=None, moments=None, steps_per_launch=None, lanes_per_chain=0, debug_flags=0, gf_per_chain=None):
     """Advance `chains` by n_steps iterations with the C-ABI entry point `entry`
     ('glabc_glmcmc_steps' / 'glabc_globalmcmc_steps'), K iterations per launch.
 
     history: None or float32 tensor [n_steps][d][C] on the chains' device.
     lanes_per_chain: 0 = let the library choose from the chain count; 1 / 2 / 4 force the
     launch geometry (results are identical for every choice).
+    gf_per_chain: None or float32 device tensor [C] replacing global_frequency chain by chain.
     """
     lib = _capi.lib()
     fn = getattr(lib, entry)
@@ -158,6 +159,8 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
             run.batch_size = int(batch_size or 1)
             run.lanes_per_chain = int(lanes_per_chain)
             run.debug_flags = int(debug_flags)
+            if gf_per_chain is not None:
+                run.global_frequency_per_chain = gf_per_chain.data_ptr()
             if history is not None:
                 run.history = history[done].data_ptr()
                 run.hist_stride = chains.n

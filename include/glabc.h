@@ -160,6 +160,9 @@ typedef struct glabc_run {
     int32_t lanes_per_chain;       /* launch geometry only, never changes results: 0 = choose from n_chains,
                                       or 1 / 2 / 4 lanes cooperating on one chain's batch_size proposals */
     int32_t debug_flags;           /* 0, or GLABC_DEBUG_* bits: execution strategy only, never changes results */
+    const float* global_frequency_per_chain;   /* NULL, or device array [n_chains] that replaces global_frequency chain by
+                                      chain -- a hyper-parameter grid (examples/Mixture_hyper.py:24) is then one launch.
+                                      glabc_glmcmc_steps / glabc_globalmcmc_steps only */
 } glabc_run;
 
 /* glabc_run.debug_flags: the iSIR index (GLMCMC.py:7-22) is normally found from float32 reciprocal-multiplied

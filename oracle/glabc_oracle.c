@@ -569,7 +569,8 @@ ORACLE_API int oracle_glmcmc_steps(const glabc_model* m, const glabc_dist* local
                 draws_from_tape(&dr, run->tape, i, t, run->n_steps, N, d, yd);
             else
                 draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, N, d, yd, 0);
-            if (dr.u_branch < run->global_frequency) {                              /* GLMCMC.py:59 */
+            const float gf = run->global_frequency_per_chain ? run->global_frequency_per_chain[i] : run->global_frequency;
+            if (dr.u_branch < gf) {                                                 /* GLMCMC.py:59 */
                 if (!run->tape && imp->kind == GLABC_DIST_UNIFORM)
                     draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, N, d, yd, 1);
                 s.n_moves += (uint32_t)isir_move(m, imp, N, &s, &dr);
@@ -630,7 +631,8 @@ ORACLE_API int oracle_globalmcmc_steps(const glabc_model* m, const glabc_dist* l
                 draws_from_tape(&dr, run->tape, i, t, run->n_steps, 1, d, yd);
             else
                 draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, yd, 0);
-            int is_global = dr.u_branch < run->global_frequency;                    /* GlobalMCMC.py:39 */
+            const float gf = run->global_frequency_per_chain ? run->global_frequency_per_chain[i] : run->global_frequency;
+            int is_global = dr.u_branch < gf;                                       /* GlobalMCMC.py:39 */
             const glabc_dist* p = is_global ? glob : local;
             if (!run->tape && p->kind == GLABC_DIST_UNIFORM)
                 draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, yd, 1);

@@ -589,6 +589,9 @@ def test_global_frequency_sweep(hip):
     assert out["esjd"].shape == (2, 4) and np.isfinite(out["resjd_mean"]).all()
     assert out["best_gf"] in (0, 0.5, 0.9, 1)
     assert out["esjd"][:, 2].mean() > out["esjd"][:, 0].mean()
+    from glabcmcmc_amd.examples.Mixture_hyper import sweep_fused
+    fused = sweep_fused(num_ite=400, chains_per_cell=1024, frequencies=[0, 0.5, 0.9, 1], seeds=[1, 2])
+    assert fused.shape == (2, 4) and np.allclose(fused.mean(0), out["esjd"].mean(0), rtol=0.15)
 
 
 def test_example_script_runs_every_sampler(hip, tmp_path):
@@ -706,3 +709,44 @@ def test_streamed_history_equals_the_in_memory_one(hip, tmp_path):
         got = np.load(path)
         assert np.array_equal(bits(got), bits(full)), block
         assert np.array_equal(bits(chains.theta.cpu().numpy()), bits(cfull.theta.cpu().numpy()))
+
+
+@pytest.mark.parametrize("algo", ["glmcmc", "globalmcmc"])
+def test_per_chain_global_frequency(hip, oracle, algo):
+    """glabc_run.global_frequency_per_chain: every chain with its own frequency (a hyper-parameter grid in one launch) --
+    against the oracle, bit for bit; a constant array equals the scalar run; GLMALA refuses the array."""
+    from glabcmcmc_amd import engine
+    cfg = dict(epsilon=0.3, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(8)
+    n, T, seed, N = 3000, 80, 21, 5 if algo == "glmcmc" else 1
+    theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+    y0 = np.abs(theta0).astype(np.float32)
+    gf = rng.choice(np.linspace(0, 1, 11), n).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev)
+    if algo == "glmcmc":
+        engine.init_weights(model, glob, chains)
+    hist = torch.empty(T, 2, n, device=dev)
+    gfg = torch.from_numpy(gf).to(dev)
+    engine.run_steps(ENTRY[algo], model, local, glob, chains, T, 1, seed, 0.123, N, history=hist, gf_per_chain=gfg)
+    torch.cuda.synchronize()
+    # oracle with the same array
+    hc = oracle_lib.HostChains(theta0, y0)
+    hh = np.zeros((T, 2, n), np.float32)
+    if algo == "glmcmc":
+        assert oracle.oracle_init_weights(C.byref(model), C.byref(glob), C.byref(hc.struct())) == 0
+    run, keep = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=0.123, batch=N, history=hh)
+    run.global_frequency_per_chain = gf.ctypes.data
+    fn = oracle.oracle_glmcmc_steps if algo == "glmcmc" else oracle.oracle_globalmcmc_steps
+    assert fn(C.byref(model), C.byref(local), C.byref(glob), C.byref(hc.struct()), C.byref(run)) == 0
+    assert np.array_equal(bits(hist.cpu().numpy()), bits(hh))
+    # a constant array is the scalar
+    a, _, _ = hip_run(algo, model, local, glob, theta0, y0, T, seed, 0.7, N)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev)
+    if algo == "glmcmc":
+        engine.init_weights(model, glob, chains)
+    engine.run_steps(ENTRY[algo], model, local, glob, chains, T, 1, seed, 0.0, N, history=hist,
+                     gf_per_chain=torch.full((n,), 0.7, device=dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(hist.cpu().numpy()), bits(a))
