@@ -1,0 +1,111 @@
+"""Randomised differential test, gfx950 kernels vs the CPU checker (not collected by pytest; run on the GPU box):
+
+    python tests/fuzz_parity.py [seconds] [seed]
+
+Random theta_dim, batch size, epsilon (1e-4 .. 10), global_frequency, Gaussian / Uniform proposals with random
+parameters, y_obs (also near zero), lanes per chain, iterations per launch, chain id offsets -- GLMCMC and GlobalMCMC
+histories, final states and streaming sums must agree with the oracle bit for bit.
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), "gl-abc-mcmc_amd")]
+import oracle_lib                                   # noqa: E402
+from glabcmcmc_amd import _capi, engine             # noqa: E402
+from glabcmcmc_amd.examples.Mixture import Mixture_set   # noqa: E402
+from helpers import bits, make_dist                 # noqa: E402
+
+
+def random_dist(rng, d, local):
+    if rng.random() < 0.65:
+        loc = np.zeros(d) if (local or rng.random() < 0.5) else rng.normal(0, 0.5, d)
+        scale = np.ones(d) if (not local and rng.random() < 0.5) else np.exp(rng.normal(-0.5 if local else 0.2, 0.6, d))
+        return ("gauss", [float(v) for v in loc], [float(v) for v in scale])
+    w = np.exp(rng.normal(-1.0 if local else 1.0, 0.5, d))
+    c = np.zeros(d) if local else rng.normal(0, 0.3, d)
+    return ("uniform", [float(v) for v in c - w], [float(v) for v in c + w])
+
+
+def one_case(rng, oracle, k):
+    d = int(rng.integers(1, 5))
+    algo = "glmcmc" if rng.random() < 0.7 else "globalmcmc"
+    N = int(rng.integers(1, 17)) if algo == "glmcmc" else 1
+    eps = float(np.exp(rng.uniform(np.log(1e-4), np.log(10))))
+    gf = float(rng.choice([0.0, 1.0, rng.random()]))
+    lspec, gspec = random_dist(rng, d, True), random_dist(rng, d, False)
+    model = Mixture_set(eps).descriptor()             # kernel constants for this epsilon; the rest is filled per dimension
+    model.theta_dim = model.y_dim = d
+    pspec = ("gauss", [0.0] * d, [1.0] * d) if rng.random() < 0.6 else \
+        ("gauss", [float(v) for v in rng.normal(0, 0.3, d)], [float(v) for v in np.exp(rng.normal(0.2, 0.4, d))])
+    if rng.random() < 0.15:
+        pspec = ("uniform", [-4.0] * d, [4.0] * d)
+    model.prior = make_dist(pspec).descriptor()
+    model.noise = make_dist(("gauss", [0.0] * d, [float(v) for v in np.exp(rng.normal(-1.5, 0.3, d))])).descriptor()
+    y_obs = [float(v) for v in rng.choice([0.0, 1e-3, 1.5, float(rng.normal(1, 1))], d)]
+    for j in range(d):
+        model.y_obs[j] = y_obs[j]
+    local, glob = make_dist(lspec).descriptor(), make_dist(gspec).descriptor()
+    n, T = int(rng.integers(1, 700)), int(rng.integers(1, 60))
+    lanes = int(rng.choice([0, 1, 2, 4])) if algo == "glmcmc" else 0
+    spl = int(rng.integers(1, T + 1))
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    theta0 = rng.normal(0, 1, (n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.normal(0, 1, (n, d))).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0)
+    if algo == "glmcmc":
+        engine.init_weights(model, glob, chains)
+    hist = torch.empty(T, d, n, device=dev)
+    mom = engine.Moments(n, d, dev)
+    entry = "glabc_glmcmc_steps" if algo == "glmcmc" else "glabc_globalmcmc_steps"
+    engine.run_steps(entry, model, local, glob, chains, T, 1, seed, gf, N, history=hist, moments=mom, steps_per_launch=spl,
+                     lanes_per_chain=lanes)
+    torch.cuda.synchronize()
+    hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
+    hh = np.zeros((T, d, n), np.float32)
+    hm = oracle_lib.HostMoments(n, d)
+    run, keep = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh, moments=hm)
+    cs = hc.struct()
+    if algo == "glmcmc":
+        assert oracle.oracle_init_weights(C.byref(model), C.byref(glob), C.byref(cs)) == 0
+        rc = oracle.oracle_glmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    else:
+        rc = oracle.oracle_globalmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    assert rc == 0
+    desc = dict(case=k, algo=algo, d=d, N=N, eps=eps, gf=gf, local=lspec, glob=gspec, prior=pspec, y_obs=y_obs,
+                n=n, T=T, lanes=lanes, spl=spl)
+    ok = np.array_equal(bits(hist.cpu().numpy()), bits(hh)) and np.array_equal(bits(chains.theta.cpu().numpy()), bits(hc.theta)) \
+        and np.array_equal(bits(chains.y.cpu().numpy()), bits(hc.y)) and np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
+    if algo == "glmcmc":
+        ok = ok and np.array_equal(bits(chains.log_w.cpu().numpy()), bits(hc.log_w)) \
+            and np.array_equal(chains.flags.cpu().numpy().astype(np.uint32), hc.flags)
+    return ok, desc, int(hc.n_moves.sum())
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    oracle = oracle_lib.load()
+    _capi.lib()
+    t0, k, moves, bad = time.time(), 0, 0, []
+    while time.time() - t0 < budget:
+        ok, desc, mv = one_case(rng, oracle, k)
+        moves += mv
+        if not ok:
+            bad.append(desc)
+            print("MISMATCH", desc, flush=True)
+        k += 1
+        if k % 50 == 0:
+            print("%d cases, %d moves, %d mismatches" % (k, moves, len(bad)), flush=True)
+    print("done: %d cases, %d accepted moves, %d mismatches" % (k, moves, len(bad)))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -750,3 +750,18 @@ def test_per_chain_global_frequency(hip, oracle, algo):
                      gf_per_chain=torch.full((n,), 0.7, device=dev))
     torch.cuda.synchronize()
     assert np.array_equal(bits(hist.cpu().numpy()), bits(a))
+
+
+def test_randomised_configurations_equal_oracle(hip, oracle):
+    """A few seconds of tests/fuzz_parity.py (random dimension, batch size, epsilon, frequencies, proposal kinds and
+    parameters, observations near zero, lanes, launch splits): kernels == oracle, bit for bit.  The script itself runs
+    for as long as asked (3842 configurations / 10 million accepted moves without a mismatch in round 1)."""
+    import time
+    import fuzz_parity
+    rng = np.random.default_rng(12345)
+    t0, k = time.time(), 0
+    while time.time() - t0 < 8.0:
+        ok, desc, _ = fuzz_parity.one_case(rng, oracle, k)
+        assert ok, desc
+        k += 1
+    assert k > 20
