@@ -4,7 +4,8 @@
 
 Random theta_dim, batch size, epsilon (1e-4 .. 10), global_frequency, Gaussian / Uniform proposals with random
 parameters, y_obs (also near zero), lanes per chain, iterations per launch, chain id offsets -- GLMCMC and GlobalMCMC
-histories, final states and streaming sums must agree with the oracle bit for bit.
+histories, final states and streaming sums must agree with the oracle bit for bit; every fourth case is GLMALA
+(random tau, num_grad, float64 state, gradients).
 """
 import ctypes as C
 import os
@@ -88,6 +89,49 @@ def one_case(rng, oracle, k):
     return ok, desc, int(hc.n_moves.sum())
 
 
+def one_case_mala(rng, oracle, k):
+    """GLMALA: float64 state after the first accepted MALA move, wave-cooperative gradient, split fixed-point sums."""
+    d = int(rng.integers(1, 5))
+    N = int(rng.integers(1, 9))
+    eps = float(np.exp(rng.uniform(np.log(0.02), np.log(3))))
+    gf = float(rng.choice([0.0, 1.0, rng.random()]))
+    tau = float(np.exp(rng.uniform(np.log(0.05), np.log(0.6))))
+    num = int(rng.integers(2, 60))
+    gspec = random_dist(rng, d, False)
+    model = Mixture_set(eps).descriptor()
+    model.theta_dim = model.y_dim = d
+    model.prior = make_dist(("gauss", [0.0] * d, [1.0] * d)).descriptor()
+    model.noise = make_dist(("gauss", [0.0] * d, [float(v) for v in np.exp(rng.normal(-1.5, 0.3, d))])).descriptor()
+    y_obs = [float(v) for v in rng.choice([0.0, 1e-3, 1.5, float(rng.normal(1, 1))], d)]
+    for j in range(d):
+        model.y_obs[j] = y_obs[j]
+    glob = make_dist(gspec).descriptor()
+    mala = _capi.Mala(tau, tau ** 2, eps ** 2, num, 0)
+    n, T = int(rng.integers(1, 200)), int(rng.integers(1, 40))
+    spl = int(rng.integers(1, T + 1))
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    theta0 = rng.normal(0, 1, (n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.normal(0, 1, (n, d))).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0).add_mala_state()
+    engine.glmala_init(model, chains)
+    hist = torch.empty(T, d, n, device=dev)
+    engine.run_glmala_steps(model, glob, mala, chains, T, 1, seed, gf, N, history=hist, steps_per_launch=spl)
+    torch.cuda.synchronize()
+    hc = oracle_lib.HostChains(theta0, y0, chain0=chain0).add_mala_state()
+    hh = np.zeros((T, d, n), np.float32)
+    run, keep = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh)
+    cs = hc.struct()
+    assert oracle.oracle_glmala_init(C.byref(model), C.byref(cs)) == 0
+    assert oracle.oracle_glmala_steps(C.byref(model), C.byref(glob), C.byref(mala), C.byref(cs), C.byref(run)) == 0
+    desc = dict(case=k, algo="glmala", d=d, N=N, eps=eps, gf=gf, tau=tau, num=num, glob=gspec, y_obs=y_obs, n=n, T=T, spl=spl)
+    ok = np.array_equal(bits(hist.cpu().numpy()), bits(hh)) and np.array_equal(chains.theta64.cpu().numpy(), hc.theta64) \
+        and np.array_equal(chains.y64.cpu().numpy(), hc.y64) and np.array_equal(chains.log_w64.cpu().numpy(), hc.log_w64) \
+        and np.array_equal(chains.grad.cpu().numpy(), hc.grad) \
+        and np.array_equal(chains.flags.cpu().numpy().astype(np.uint32), hc.flags)
+    return ok, desc, int(hc.n_moves.sum())
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -95,7 +139,7 @@ def main():
     _capi.lib()
     t0, k, moves, bad = time.time(), 0, 0, []
     while time.time() - t0 < budget:
-        ok, desc, mv = one_case(rng, oracle, k)
+        ok, desc, mv = (one_case_mala if k % 4 == 3 else one_case)(rng, oracle, k)
         moves += mv
         if not ok:
             bad.append(desc)
