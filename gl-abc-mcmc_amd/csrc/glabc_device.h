@@ -242,7 +242,9 @@ GLABC_DEV void model_simulate(const StepArgs<D, YD>& a, const float (&theta)[D],
         for (int j = 0; j < YD; ++j) {
             const float z = eps[j];
             const float t = gk_tanhf((theta[2] * z) * 0.5f);
-            const float pw = glabc_expf(theta[3] * glabc_logf(1.0f + z * z));
+            // z is a Box-Muller normal (|z| < 7), so 1 + z^2 is a normal float in [1, 50]: the special-case-free log
+            // returns glabc_logf's bits with 10 instructions less, 40 times per step
+            const float pw = glabc_expf(theta[3] * glabc_logf_normal(1.0f + z * z));
             y[j] = theta[0] + ((theta[1] * (1.0f + a.gk_c * t)) * pw) * z;
         }
         sort_ascending<YD>(y);
