@@ -5,7 +5,7 @@
 Random theta_dim, batch size, epsilon (1e-4 .. 10), global_frequency, Gaussian / Uniform proposals with random
 parameters, y_obs (also near zero), lanes per chain, iterations per launch, chain id offsets -- GLMCMC and GlobalMCMC
 histories, final states and streaming sums must agree with the oracle bit for bit; every fourth case is GLMALA
-(random tau, num_grad, float64 state, gradients).
+(random tau, num_grad, float64 state, gradients), every eighth the g-and-k Model.
 """
 import ctypes as C
 import os
@@ -132,6 +132,48 @@ def one_case_mala(rng, oracle, k):
     return ok, desc, int(hc.n_moves.sum())
 
 
+def one_case_gk(rng, oracle, k):
+    """GLMCMC / GlobalMCMC on the g-and-k Model (theta_dim 4, y_dim 8: exp / tanh / pow per variate, sorted data)."""
+    from glabcmcmc_amd.examples.GK import GK_set
+    algo = "glmcmc" if rng.random() < 0.8 else "globalmcmc"
+    N = int(rng.integers(1, 9)) if algo == "glmcmc" else 1
+    eps = float(np.exp(rng.uniform(np.log(0.1), np.log(5))))
+    gf = float(rng.choice([0.0, 1.0, rng.random()]))
+    model = GK_set(eps).descriptor()
+    lspec = ("gauss", [0.0] * 4, [float(v) for v in np.exp(rng.normal(-1.8, 0.4, 4))]) if rng.random() < 0.7 else \
+        ("uniform", [-0.3] * 4, [0.3] * 4)
+    gspec = ("uniform", [0.0] * 4, [10.0] * 4) if rng.random() < 0.6 else \
+        ("gauss", [3.0, 1.5, 2.0, 1.0], [float(v) for v in np.exp(rng.normal(0.3, 0.3, 4))])
+    local, glob = make_dist(lspec).descriptor(), make_dist(gspec).descriptor()
+    n, T = int(rng.integers(1, 300)), int(rng.integers(1, 40))
+    lanes = int(rng.choice([0, 1, 2, 4])) if algo == "glmcmc" else 0
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    theta0 = rng.uniform(0.5, 5, (n, 4)).astype(np.float32)
+    y0 = np.sort(rng.normal(3, 2, (n, 8)), axis=1).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0)
+    if algo == "glmcmc":
+        engine.init_weights(model, glob, chains)
+    hist = torch.empty(T, 4, n, device=dev)
+    entry = "glabc_glmcmc_steps" if algo == "glmcmc" else "glabc_globalmcmc_steps"
+    engine.run_steps(entry, model, local, glob, chains, T, 1, seed, gf, N, history=hist, lanes_per_chain=lanes)
+    torch.cuda.synchronize()
+    hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
+    hh = np.zeros((T, 4, n), np.float32)
+    run, keep = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh)
+    cs = hc.struct()
+    if algo == "glmcmc":
+        assert oracle.oracle_init_weights(C.byref(model), C.byref(glob), C.byref(cs)) == 0
+        rc = oracle.oracle_glmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    else:
+        rc = oracle.oracle_globalmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    assert rc == 0
+    desc = dict(case=k, algo=algo + "-gk", N=N, eps=eps, gf=gf, local=lspec, glob=gspec, n=n, T=T, lanes=lanes)
+    ok = np.array_equal(bits(hist.cpu().numpy()), bits(hh)) and np.array_equal(bits(chains.theta.cpu().numpy()), bits(hc.theta)) \
+        and np.array_equal(bits(chains.y.cpu().numpy()), bits(hc.y))
+    return ok, desc, int(hc.n_moves.sum())
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -139,7 +181,7 @@ def main():
     _capi.lib()
     t0, k, moves, bad = time.time(), 0, 0, []
     while time.time() - t0 < budget:
-        ok, desc, mv = (one_case_mala if k % 4 == 3 else one_case)(rng, oracle, k)
+        ok, desc, mv = (one_case_mala if k % 4 == 3 else one_case_gk if k % 8 == 5 else one_case)(rng, oracle, k)
         moves += mv
         if not ok:
             bad.append(desc)
