@@ -174,6 +174,35 @@ def one_case_gk(rng, oracle, k):
     return ok, desc, int(hc.n_moves.sum())
 
 
+def one_case_nf(rng, oracle, k):
+    """The RealNVP coupling stack on the matrix cores (tile mode up to 8192 rows, pair mode above) vs the oracle."""
+    from glabcmcmc_amd.flows import RealNVP
+    nc = int(rng.integers(1, 5))
+    n = int(rng.choice([rng.integers(1, 400), rng.integers(8100, 8300), rng.integers(8193, 30000), rng.integers(65000, 70000)]))
+    torch.manual_seed(int(rng.integers(0, 2 ** 31)))
+    flow = RealNVP(nc)
+    with torch.no_grad():
+        for c in flow.couplings:
+            c.l3.weight.normal_(0, float(rng.uniform(0.05, 0.5)) / 128 ** 0.5)
+            c.l3.bias.normal_(0, 0.1)
+        flow.q0.loc.copy_(torch.tensor([[float(rng.normal(0, 0.3)), float(rng.normal(0, 0.3))]]))
+        flow.q0.log_scale.copy_(torch.tensor([[float(rng.normal(0, 0.2)), float(rng.normal(0, 0.2))]]))
+    blob = flow.packed_params().numpy().copy()
+    f = flow.descriptor(torch.from_numpy(blob))
+    f.params = blob.ctypes.data
+    seed, row0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    z, lq, lp = np.empty((2, n), np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
+    assert oracle.oracle_nf_sample(C.byref(f), None, seed, row0, n, z.ctypes.data, lq.ctypes.data) == 0
+    assert oracle.oracle_nf_log_prob(C.byref(f), z.ctypes.data, n, lp.ctypes.data) == 0
+    g = flow.cuda()
+    zg, lqg = g.sample(n, seed=seed, row0=row0)
+    lpg = g.log_prob(zg)
+    torch.cuda.synchronize()
+    ok = np.array_equal(bits(zg.cpu().numpy()), bits(z.T)) and np.array_equal(bits(lqg.cpu().numpy()), bits(lq)) \
+        and np.array_equal(bits(lpg.cpu().numpy()), bits(lp))
+    return ok, dict(case=k, algo="nf", couplings=nc, rows=n), 0
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -181,7 +210,8 @@ def main():
     _capi.lib()
     t0, k, moves, bad = time.time(), 0, 0, []
     while time.time() - t0 < budget:
-        ok, desc, mv = (one_case_mala if k % 4 == 3 else one_case_gk if k % 8 == 5 else one_case)(rng, oracle, k)
+        fn = one_case_mala if k % 4 == 3 else one_case_gk if k % 8 == 5 else one_case_nf if k % 32 == 9 else one_case
+        ok, desc, mv = fn(rng, oracle, k)
         moves += mv
         if not ok:
             bad.append(desc)
