@@ -201,7 +201,9 @@ GLABC_DEV float dist_forward_log_p(const DistArgs<D>& g, const float (&noise)[D]
 // tanh and x^k for the g-and-k quantile function, spelled with the specified exp / log
 GLABC_DEV float gk_tanhf(float x)
 {
-    const float e = glabc_expf(-2.0f * __builtin_fabsf(x));
+    // exp of a finite non-positive argument: the clamp at -104 is all glabc_expf adds to its core there (same bits,
+    // four instructions less, 40 times per step)
+    const float e = glabc_expf_core(__builtin_fmaxf(-2.0f * __builtin_fabsf(x), -104.0f));
     const float r = (1.0f - e) / (1.0f + e);
     return x < 0.0f ? -r : r;
 }
