@@ -182,7 +182,8 @@ __global__ void __launch_bounds__(256) kde_log_prob_kernel(const KdeArgs<D> a)
         // pass 2: exact fixed-point sum of exp(lk - max); every term is in [0, 1]
         int64_t acc = 0;
         for (int64_t s = lane; s < a.n_samples; s += 64) {
-            const float e = glabc_expf(kde_log_term<D>(a, pt, inv, s) - m0);
+            // the argument is <= 0 and not NaN here: glabc_expf reduces to its core behind the clamp (same bits)
+            const float e = glabc_expf_core(__builtin_fmaxf(kde_log_term<D>(a, pt, inv, s) - m0, -104.0f));
             acc += glabc_fx_quantize((double)e);
         }
 #pragma unroll
