@@ -170,6 +170,149 @@ GLABC_DEV double shfl_f64(double v, int src)
 
 // numberical_gradient_logABC, GLMALA.py:46-95, wave-cooperative.
 //
+// LDS of one wavefront's gradient work (one wavefront per workgroup)
+struct GradShared {
+    unsigned long long acc[64][8];   // theta_dim 2: per needing chain (s1, a, b, c) of the + and the - side, glabc_fxsplit
+    float th[64][2];                 //              its theta
+    uint32_t c0[64], c1[64];         //              its Philox counter words (global chain id)
+    int srcmap[64];                  // rank -> lane of the needing chains
+};
+
+// theta_dim 2: the n needing chains' work -- per coordinate n x nb Philox blocks of two simulations each -- is dealt to
+// the 64 lanes as CONTIGUOUS ranges of ceil(n nb / 64) items, whatever n is (lane groups of a power of two leave up to a
+// third of the wavefront idle: 13 chains -> 16 groups of 4 lanes, 13 rounds instead of 10.4).  A lane's range touches at
+// most two chains; it keeps the current chain's partial sums in registers and adds them to that chain's accumulators in
+// LDS (64-bit integer atomics: exact, order-free) when the chain changes and at the end; the owners then finish the
+// statistics of their own chain.
+template <bool LEAN>
+GLABC_DEV void coop_gradient_flat2(const MalaArgs<2>& m, const Rng& rng, uint32_t step, int g, bool need, unsigned long long mask,
+                                   const float (&theta)[2], double (&grad)[2], GradShared* sh)
+{
+    constexpr int D = 2;
+    const StepArgs<D>& a = m.s;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int n = __popcll(mask);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const int num = m.num_grad;
+    const float h = 0.1f, hp = 0.00001f;
+    __syncthreads();                                                    // earlier readers of the shared block are done
+    if (need) {
+        sh->th[rank][0] = theta[0];
+        sh->th[rank][1] = theta[1];
+        sh->c0[rank] = rng.c0;
+        sh->c1[rank] = rng.c1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh->acc[rank][j] = 0ull;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < D; ++k) {
+        const int64_t first = (int64_t)k * num;                         // global simulation index of s = 0
+        const int64_t b_lo = first >> 1, b_hi = (first + num - 1) >> 1; // a Philox block = the normals of two simulations
+        const int nb = (int)(b_hi - b_lo + 1);
+        const int total = n * nb;
+        const int q = (total + 63) >> 6;
+        const int it0 = lane * q;
+        const int it1 = (it0 + q < total) ? it0 + q : total;
+        int cur = (it0 < total) ? it0 / nb : 0, bi = (it0 < total) ? it0 - cur * nb : 0;
+        float tp[D], tm[D];
+        double c_p = 0.0, c_m = 0.0;
+        uint32_t cc0 = 0u, cc1 = 0u;
+        glabc_fxsplit ap = {0, 0, 0, 0}, am = {0, 0, 0, 0};
+        auto enter = [&](int c) {                                      // this coordinate's constants of chain c
+            float th[D], zero[D], y0p[D], y0m[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                th[j] = sh->th[c][j];
+                tp[j] = th[j] + (j == k ? h : 0.0f);                    // GLMALA.py:67
+                tm[j] = th[j] - (j == k ? h : 0.0f);                    // GLMALA.py:68
+                zero[j] = 0.0f;
+            }
+            model_simulate<D>(a, tp, zero, y0p);                        // centres: the noise-free discrepancies
+            model_simulate<D>(a, tm, zero, y0m);
+            c_p = (double)model_discrepancy<D, LEAN>(a, y0p);
+            c_m = (double)model_discrepancy<D, LEAN>(a, y0m);
+            cc0 = sh->c0[c];
+            cc1 = sh->c1[c];
+        };
+        auto flush = [&](int c) {
+            atomicAdd(&sh->acc[c][0], (unsigned long long)ap.s1);
+            atomicAdd(&sh->acc[c][1], ap.a);
+            atomicAdd(&sh->acc[c][2], (unsigned long long)ap.b);
+            atomicAdd(&sh->acc[c][3], ap.c);
+            atomicAdd(&sh->acc[c][4], (unsigned long long)am.s1);
+            atomicAdd(&sh->acc[c][5], am.a);
+            atomicAdd(&sh->acc[c][6], (unsigned long long)am.b);
+            atomicAdd(&sh->acc[c][7], am.c);
+            ap = glabc_fxsplit{0, 0, 0, 0};
+            am = glabc_fxsplit{0, 0, 0, 0};
+        };
+        auto one_sim = [&](const float (&eps)[D]) {
+            float yp[D], ym[D];
+            model_simulate<D>(a, tp, eps, yp);                          // GLMALA.py:78
+            model_simulate<D>(a, tm, eps, ym);                          // GLMALA.py:82 (same noise)
+            glabc_fxs_add(&ap, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, yp) - c_p));
+            glabc_fxs_add(&am, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, ym) - c_m));
+        };
+        if (it0 < it1) enter(cur);
+#pragma unroll 1
+        for (int it = it0; it < it1; ++it) {
+            const int64_t b = b_lo + bi;
+            glabc_u32x4 blk = glabc_philox4x32_10(cc0, cc1, step, GRAD_BASE + (uint32_t)g * GRAD_STRIDE + (uint32_t)b, rng.k0, rng.k1);
+            float e0[2], e1[2];
+            glabc_normal_pair(blk.v[0], blk.v[1], &e0[0], &e0[1]);
+            glabc_normal_pair(blk.v[2], blk.v[3], &e1[0], &e1[1]);
+            const int64_t s0 = 2 * b - first, s1 = s0 + 1;              // simulation indices within coordinate k
+            if (s0 >= 0 && s0 < num) one_sim(e0);
+            if (s1 >= 0 && s1 < num) one_sim(e1);
+            if (++bi == nb && it + 1 < it1) {                           // the range crosses into the next chain
+                flush(cur);
+                bi = 0;
+                ++cur;
+                enter(cur);
+            }
+        }
+        if (it0 < it1) flush(cur);
+        __syncthreads();
+        if (need) {                                                     // the owner finishes its chain's coordinate k
+            glabc_fxsplit sp, sm;
+            sp.s1 = (int64_t)sh->acc[rank][0]; sp.a = sh->acc[rank][1]; sp.b = (int64_t)sh->acc[rank][2]; sp.c = sh->acc[rank][3];
+            sm.s1 = (int64_t)sh->acc[rank][4]; sm.a = sh->acc[rank][5]; sm.b = (int64_t)sh->acc[rank][6]; sm.c = sh->acc[rank][7];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sh->acc[rank][j] = 0ull;        // ready for the next coordinate
+            float op[D], om[D], zero[D], y0p[D], y0m[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                op[j] = theta[j] + (j == k ? h : 0.0f);
+                om[j] = theta[j] - (j == k ? h : 0.0f);
+                zero[j] = 0.0f;
+            }
+            model_simulate<D>(a, op, zero, y0p);
+            model_simulate<D>(a, om, zero, y0m);
+            const double o_p = (double)model_discrepancy<D, LEAN>(a, y0p), o_m = (double)model_discrepancy<D, LEAN>(a, y0m);
+            const glabc_fxsum fp = glabc_fxs_finish(&sp), fm = glabc_fxs_finish(&sm);
+            const double nd = (double)num;
+            const double s1p = glabc_fx_sum1(&fp), s2p = glabc_fx_sum2(&fp), s1m = glabc_fx_sum1(&fm), s2m = glabc_fx_sum2(&fm);
+            const double mu_p = o_p + s1p / nd, mu_m = o_m + s1m / nd;                           // GLMALA.py:86-87
+            const double var_p = (s2p - (s1p * s1p) / nd) / (nd - 1.0), var_m = (s2m - (s1m * s1m) / nd) / (nd - 1.0);   // :88-89
+            const double lp = (-0.5 * glabc_log(var_p + m.eps_sq)) - ((0.5 * (mu_p * mu_p)) / (var_p + m.eps_sq));   // :90-91
+            const double lm = (-0.5 * glabc_log(var_m + m.eps_sq)) - ((0.5 * (mu_m * mu_m)) / (var_m + m.eps_sq));   // :92-93
+            const double gll = (lp - lm) / 0.2;                                                  // :94
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                op[j] = theta[j] + (j == k ? hp : 0.0f);                                         // :84
+                om[j] = theta[j] - (j == k ? hp : 0.0f);
+            }
+            const float gp = (dist_log_prob<D>(a.prior, op) - dist_log_prob<D>(a.prior, om)) / 0.00002f;   // :84-85
+            const double gk = gll + (double)gp;                                                  // :95
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                if (j == k) grad[j] = gk;
+        }
+        __syncthreads();                                                // accumulators are zero again before anyone adds
+    }
+}
+
 // Every lane of the wavefront calls this; `need` marks the lanes (chains) that want the gradient of their `theta`
 // (float32, GLMALA.py:62).  The n needing chains are dealt to lane groups of G = 64 / 2^ceil(log2 n) lanes; the
 // lanes of a group split the chain's num_grad simulations per coordinate (s = sub, sub + G, ...), accumulate the
@@ -178,11 +321,16 @@ GLABC_DEV double shfl_f64(double v, int src)
 // srcmap: 64 ints of LDS (one wavefront per workgroup).
 template <int D, bool LEAN = false>
 GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step, int g, bool need, const float (&theta)[D],
-                             double (&grad)[D], int* srcmap)
+                             double (&grad)[D], GradShared* sh)
 {
     const StepArgs<D>& a = m.s;
     const unsigned long long mask = __ballot(need);
     if (mask == 0ull) return;                                           // wave-uniform
+    if constexpr (D == 2) {
+        coop_gradient_flat2<LEAN>(m, rng, step, g, need, mask, theta, grad, sh);
+        return;
+    }
+    int* srcmap = sh->srcmap;
     const int lane = (int)(threadIdx.x & 63u);
     const int n = __popcll(mask);
     int G = 64;
@@ -311,14 +459,14 @@ GLABC_DEV void coop_gradient(const MalaArgs<D>& m, const Rng& rng, uint32_t step
 // `is_local` marks the chains that take the move this iteration.
 template <int D, bool LEAN = false>
 GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, bool is_local, float u_accept,
-                         const float (&zn)[2 * D], MalaChain<D>& c, int* srcmap)
+                         const float (&zn)[2 * D], MalaChain<D>& c, GradShared* sh)
 {
     const StepArgs<D>& a = m.s;
     float thf[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) thf[j] = (float)c.theta[j];
     const bool init = is_local && !(c.flags & GLABC_FLAG_HAS_GRAD);                          // :183-184
-    coop_gradient<D, LEAN>(m, rng, step, 0, init, thf, c.grad, srcmap);
+    coop_gradient<D, LEAN>(m, rng, step, 0, init, thf, c.grad, sh);
     if (init) c.flags |= GLABC_FLAG_HAS_GRAD;
     // Local_proposal_forward, :25-44
     float t[D];
@@ -340,7 +488,7 @@ GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, bo
         thf[j] = (float)x[j];                                                                // :62
         gprop[j] = 0.0;
     }
-    coop_gradient<D, LEAN>(m, rng, step, 1, is_local, thf, gprop, srcmap);                         // :187
+    coop_gradient<D, LEAN>(m, rng, step, 1, is_local, thf, gprop, sh);                         // :187
     if (!is_local) return false;
     double y[D];
 #pragma unroll
@@ -476,7 +624,7 @@ template <int D, int N, bool LEAN>
 __global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
 {
     const StepArgs<D>& a = m.s;
-    __shared__ int srcmap[64];
+    __shared__ GradShared gsh;
     const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool valid = tid < a.n_chains;
     const int64_t i = valid ? tid : a.n_chains - 1;          // tail lanes shadow the last chain (no stores): the cooperative
@@ -532,7 +680,7 @@ __global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
                 zn[j] = e[j];
                 zn[D + j] = s[j];
             }
-            const bool mv = mala_move<D, LEAN>(m, rng, step, !is_global && valid, glabc_uniform_f32(h.v[1]), zn, c, srcmap);
+            const bool mv = mala_move<D, LEAN>(m, rng, step, !is_global && valid, glabc_uniform_f32(h.v[1]), zn, c, &gsh);
             moved = is_global ? moved : mv;
         }
         c.n_moves += moved ? 1u : 0u;
