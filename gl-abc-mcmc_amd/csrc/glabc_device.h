@@ -391,7 +391,12 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
     // (Philox slot 0) is drawn there, in the same instruction stream as the other lanes'
     // candidates of that pass, and that pass runs first so candidate 0 knows its branch.
     constexpr bool FREE_SLOT = (L > 1) && (N % L != 0) && (NL >= 2);
-    constexpr int M = D + YD;                          // draws per candidate: D proposal + YD simulator
+    // Draws per candidate: D proposal draws (words 0..D-1), then YD simulator normals starting at the next EVEN word
+    // index DP: normals come in Box-Muller pairs from words (2i, 2i+1), and a Uniform proposal turns each of its words into
+    // one [0,1) draw -- a simulator normal must never share a word with a proposal draw (theta' and y' would not be
+    // independent; with odd D and the pair straddling the boundary they were not)
+    constexpr int DP = D + (D & 1);
+    constexpr int M = DP + YD;
     constexpr int SPP = (M + 3) / 4;
 
     uint32_t hw[4];
@@ -436,7 +441,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         const int j = sub + L * r;                  // candidate index of this slot (>= N: unused slot)
         const bool head_pass = FREE_SLOT && (r == NL - 1);
         const bool first = (r == 0) && (L == 1 || sub == 0);                  // candidate 0 doubles as the local move
-        // Philox blocks of this slot: D proposal draws then D simulator draws out of ceil(2D/4)
+        // Philox blocks of this slot: D proposal draws then (from word DP) YD simulator draws out of SPP
         // blocks at slots 1 + j*SPP + b; normals in Box-Muller pairs from words (2i, 2i+1)
         uint32_t w[4 * SPP];
 #pragma unroll
@@ -460,9 +465,9 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
 #pragma unroll
         for (int i = 0; i < D; ++i) e[i] = (!GU && uni) ? glabc_uniform_f32(w[i]) : nrm[i];
 #pragma unroll
-        for (int i = 0; i < YD; ++i) s[i] = nrm[D + i];
+        for (int i = 0; i < YD; ++i) s[i] = nrm[DP + i];
         if constexpr (TAPE) {                       // the tape holds this candidate's draws in the same order
-            const float* tz = a.tape_z + (tape_pos * a.tape_nprop + (j < a.tape_nprop ? j : 0)) * M;
+            const float* tz = a.tape_z + (tape_pos * a.tape_nprop + (j < a.tape_nprop ? j : 0)) * (D + YD);
 #pragma unroll
             for (int i = 0; i < D; ++i) e[i] = tz[i];
 #pragma unroll

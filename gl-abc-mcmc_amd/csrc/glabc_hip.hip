@@ -374,7 +374,8 @@ __global__ void __launch_bounds__(64) nf_step_kernel(const PoolArgs<D> p)
         kk += 1;                                                                        // :111
     } else {                                                                            // :141-152
         float e[D], s[D], tn[D], yn[D];
-        constexpr int SPP = (2 * D + 3) / 4;
+        constexpr int DP = D + (D & 1);                       // simulator normals start at an even word (glabc_device.h)
+        constexpr int SPP = (DP + D + 3) / 4;
         uint32_t wd[4 * SPP];
 #pragma unroll
         for (int b = 0; b < SPP; ++b) {
@@ -382,14 +383,14 @@ __global__ void __launch_bounds__(64) nf_step_kernel(const PoolArgs<D> p)
 #pragma unroll
             for (int q = 0; q < 4; ++q) wd[4 * b + q] = o.v[q];
         }
-        float nrm[2 * D];
+        float nrm[4 * SPP];
 #pragma unroll
-        for (int q = 0; q < D; ++q) glabc_normal_pair(wd[2 * q], wd[2 * q + 1], &nrm[2 * q], &nrm[2 * q + 1]);
+        for (int q = 0; q < 2 * SPP; ++q) glabc_normal_pair(wd[2 * q], wd[2 * q + 1], &nrm[2 * q], &nrm[2 * q + 1]);
         const bool uni = a.local.kind == GLABC_DIST_UNIFORM;
 #pragma unroll
         for (int q = 0; q < D; ++q) {
             e[q] = uni ? glabc_uniform_f32(wd[q]) : nrm[q];
-            s[q] = nrm[D + q];
+            s[q] = nrm[DP + q];
             tn[q] = (a.local.p0[q] + a.local.p2[q] * e[q]) + th[q];                     // :142
         }
         model_simulate<D>(a, tn, s, yn);

@@ -523,11 +523,13 @@ GLABC_DEV bool mala_move(const MalaArgs<D>& m, const Rng& rng, uint32_t step, bo
     return false;
 }
 
-// Philox blocks of candidate j: D proposal draws then D simulator draws (same layout as GLMCMC)
+// Philox blocks of candidate j: D proposal draws, then D simulator draws from the next even word (same layout as GLMCMC,
+// glabc_device.h chain_step)
 template <int D>
 GLABC_DEV void candidate_draws(const Rng& rng, uint32_t step, int j, bool uniform_prop, float (&e)[D], float (&s)[D])
 {
-    constexpr int SPP = (2 * D + 3) / 4;
+    constexpr int DP = D + (D & 1);
+    constexpr int SPP = (DP + D + 3) / 4;
     uint32_t w[4 * SPP];
 #pragma unroll
     for (int b = 0; b < SPP; ++b) {
@@ -535,13 +537,13 @@ GLABC_DEV void candidate_draws(const Rng& rng, uint32_t step, int j, bool unifor
 #pragma unroll
         for (int q = 0; q < 4; ++q) w[4 * b + q] = o.v[q];
     }
-    float nrm[2 * D];
+    float nrm[4 * SPP];
 #pragma unroll
-    for (int i = 0; i < D; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
+    for (int i = 0; 2 * i < DP + D; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         e[i] = uniform_prop ? glabc_uniform_f32(w[i]) : nrm[i];
-        s[i] = nrm[D + i];
+        s[i] = nrm[DP + i];
     }
 }
 

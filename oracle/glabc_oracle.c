@@ -342,9 +342,11 @@ typedef struct step_draws {
 } step_draws;
 
 /* Philox slots of one (chain, step): slot 0 = {branch, accept, resample hi, resample lo};
- * proposal j uses slots 1 + j*spp .. , spp = ceil((d + y_dim)/4) blocks, consecutive u32 pairs
- * feeding Box-Muller (DiagGaussian proposal) or single u32 -> [0,1) (Uniform proposal) for the
- * first d draws; simulator draws are always normal. */
+ * proposal j uses slots 1 + j*spp .. , spp = ceil((dp + y_dim)/4) blocks, dp = d rounded up to even:
+ * words 0..d-1 are the proposal draws -- consecutive u32 pairs feeding Box-Muller (DiagGaussian
+ * proposal) or single u32 -> [0,1) (Uniform proposal) -- and the simulator's normals start at word
+ * dp, so that no simulator normal shares a word with a proposal draw (with odd d a Box-Muller pair
+ * would otherwise straddle the boundary and y' would depend on a Uniform proposal's theta'). */
 static void draws_from_philox(step_draws* s, uint64_t seed, uint64_t chain, uint32_t step, int n_prop, int d, int yd,
                               int prop_uniform)
 {
@@ -354,7 +356,8 @@ static void draws_from_philox(step_draws* s, uint64_t seed, uint64_t chain, uint
     s->u_branch = glabc_uniform_f32(h.v[0]);
     s->u_accept = glabc_uniform_f32(h.v[1]);
     s->u_resample = glabc_uniform_f64(h.v[2], h.v[3]);
-    int m = d + yd;
+    int dp = d + (d & 1);
+    int m = dp + yd;
     int spp = (m + 3) / 4;
     for (int j = 0; j < n_prop; ++j) {
         uint32_t w[4 * ((2 * GLABC_MAX_DIM + 3) / 4)];
@@ -362,11 +365,11 @@ static void draws_from_philox(step_draws* s, uint64_t seed, uint64_t chain, uint
             glabc_u32x4 r = glabc_philox4x32_10(c0, c1, step, (uint32_t)(1 + j * spp + b), k0, k1);
             for (int q = 0; q < 4; ++q) w[4 * b + q] = r.v[q];
         }
-        /* normals are made in pairs from words (2i, 2i+1); a pair may straddle the
-         * proposal/simulator boundary when d is odd */
+        /* normals are made in pairs from words (2i, 2i+1) */
         float nrm[4 * ((2 * GLABC_MAX_DIM + 3) / 4)];
         for (int i = 0; 2 * i < 4 * spp; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
-        for (int i = 0; i < m; ++i) s->z[j][i] = nrm[i];
+        for (int i = 0; i < d; ++i) s->z[j][i] = nrm[i];
+        for (int i = 0; i < yd; ++i) s->z[j][d + i] = nrm[dp + i];
         if (prop_uniform)
             for (int i = 0; i < d; ++i) s->z[j][i] = glabc_uniform_f32(w[i]);
     }

@@ -175,7 +175,7 @@ def philox_tape(L, seed, chain, T, P, d, yd, uniform_prop_global, uniform_prop_l
         is_global = u2[0] < np.float32(gf)
         if (uniform_prop_global and is_global) or (uniform_prop_local and not is_global):
             # a Uniform proposal takes the raw words of its slots as [0,1) uniforms
-            spp = (d + yd + 3) // 4
+            spp = (d + (d & 1) + yd + 3) // 4
             key = np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)
             for j in range(P):
                 words = []
