@@ -14,16 +14,33 @@ global generator), ``device``, ``chain0`` (global id of the first chain -- the s
 offset in a multi-GPU run), ``record_history`` (False: return None, keep only
 ``stats``), ``stats`` (an ``engine.Moments`` to accumulate ESJD / moment sums into),
 ``return_device`` (leave the result on the GPU), ``steps_per_launch``, ``verbose``.
+
+Dispatch (``path``): a Model and proposals that describe themselves (``descriptor()``; theta_dim 1..4 or the g-and-k
+shape; batch_size <= 16) run in the fused kernel; ANY other Model object implementing the reference's callbacks
+(``generate_samples / prior_log_prob / calculate_log_kernel``, examples/Mixture.py:5-53), any theta_dim, any batch_size
+and any proposal object run through the split-phase path of ``generic.py`` (``glabc_propose`` -> callbacks ->
+``glabc_select``).  ``path="generic"`` forces the latter; ``path="fused"`` raises instead of falling back.
+Generic-path extras: ``callback_device`` ('auto' | 'cuda' | 'cpu'), ``sentinel_redraw`` (GLMCMC.py:92-93, default on).
 """
-from . import _host, engine
+from . import _capi, _host, engine, generic
 
 
 def GLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
            filelocation, global_frequency=0, Importance_Proposal=None, batch_size=None, *,
            seed=None, device=None, chain0=0, record_history=True, stats=None, return_device=False,
-           steps_per_launch=None, verbose=True, state_out=None):
+           steps_per_launch=None, verbose=True, state_out=None, path="auto", **generic_kw):
     if Importance_Proposal is None or batch_size is None:
         raise ValueError("GLMCMC needs Importance_Proposal and batch_size (GLMCMC.py:54,66)")
+    if path not in ("auto", "fused", "generic"):
+        raise ValueError("path must be 'auto', 'fused' or 'generic'")
+    if path == "generic" or (path == "auto" and not generic.fused_supported(ABCset, (Local_Proposal, Importance_Proposal),
+                                                                             batch_size)):
+        return generic.run(_capi.ALGO_GLMCMC, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Importance_Proposal,
+                           filelocation, global_frequency, batch_size, "glmcmc", seed=seed, device=device, chain0=chain0,
+                           record_history=record_history, stats=stats, return_device=return_device, verbose=verbose,
+                           state_out=state_out, **generic_kw)
+    if generic_kw:
+        raise TypeError("unexpected keyword arguments for the fused path: %s" % sorted(generic_kw))
     model = engine.model_descriptor(ABCset)
     local = Local_Proposal.descriptor()
     imp = Importance_Proposal.descriptor()

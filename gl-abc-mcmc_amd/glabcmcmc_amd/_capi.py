@@ -165,6 +165,33 @@ class Tape(C.Structure):
     ]
 
 
+class StepIO(C.Structure):
+    """struct glabc_step_io"""
+    _fields_ = [
+        ("n_prop", C.c_int32),
+        ("theta_dim", C.c_int32),
+        ("y_dim", C.c_int32),
+        ("noise_dim", C.c_int32),
+        ("theta_prop", C.c_void_p),
+        ("log_q", C.c_void_p),
+        ("sim_noise", C.c_void_p),
+        ("log_u", C.c_void_p),
+        ("u_res", C.c_void_p),
+        ("is_global", C.c_void_p),
+        ("y_prop", C.c_void_p),
+        ("prior_prop", C.c_void_p),
+        ("kern_prop", C.c_void_p),
+        ("prior_cur", C.c_void_p),
+        ("kern_cur", C.c_void_p),
+        ("q_cur", C.c_void_p),
+    ]
+
+
+ALGO_GLMCMC = 0
+ALGO_GLOBALMCMC = 1
+SLOT_REDRAW = 0x40000000
+
+
 class Run(C.Structure):
     """struct glabc_run"""
     _fields_ = [
@@ -202,6 +229,11 @@ ENTRY_POINTS = {
     "glabc_kde_sample": (C.c_int, [_P(Kde), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_kde_train_weights": (C.c_int, [_P(Model), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_init_weights": (C.c_int, [_P(Model), _P(Dist), _P(Chains), C.c_void_p]),
+    "glabc_propose": (C.c_int, [C.c_int, _P(Dist), _P(Dist), _P(Chains), _P(Run), _P(StepIO), C.c_void_p]),
+    "glabc_propose_redraw": (C.c_int, [_P(Dist), _P(Chains), _P(Run), _P(StepIO), C.c_int32, C.c_void_p, C.c_void_p]),
+    "glabc_select": (C.c_int, [C.c_int, _P(Dist), _P(Chains), _P(Run), _P(StepIO), C.c_void_p]),
+    "glabc_model_simulate": (C.c_int, [_P(Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_void_p,
+                                       C.c_void_p]),
     "glabc_dist_log_prob": (C.c_int, [_P(Dist), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_dist_forward": (C.c_int, [_P(Dist), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "glabc_gamma_log_prob": (C.c_int, [_P(GammaDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

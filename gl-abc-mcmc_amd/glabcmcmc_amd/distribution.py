@@ -48,6 +48,19 @@ def _launch_rowwise(fn_name, desc, z, what):
     return out
 
 
+def _launch_simulate(desc, theta, eps):
+    """glabc_model_simulate on CUDA tensors: theta (n, theta_dim), eps (n, y_dim) standard normals -> y (n, y_dim)"""
+    lib = _capi.lib()
+    th = theta.detach().to(torch.float32).reshape(-1, desc.theta_dim).contiguous()
+    ee = eps.detach().to(torch.float32).reshape(th.shape[0], desc.y_dim).contiguous()
+    y = torch.empty(th.shape[0], desc.y_dim, dtype=torch.float32, device=theta.device)
+    stream = torch.cuda.current_stream(theta.device).cuda_stream
+    with torch.cuda.device(theta.device):
+        _capi.check(lib.glabc_model_simulate(C.byref(desc), th.data_ptr(), ee.data_ptr(), th.shape[0], 0, 0, y.data_ptr(),
+                                             C.c_void_p(stream)), "glabc_model_simulate")
+    return y
+
+
 class BaseDistribution:
     """distribution.py:7-48"""
 

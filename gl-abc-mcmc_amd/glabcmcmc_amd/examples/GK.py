@@ -18,7 +18,7 @@ import torch
 
 from .. import _capi
 from .. import distribution
-from ..distribution import _fill, _launch_rowwise
+from ..distribution import _fill, _launch_rowwise, _launch_simulate
 
 Y_DIM = 8
 TRUE_THETA = (3.0, 1.0, 2.0, 0.5)
@@ -51,6 +51,15 @@ class GK_set:
         z = torch.randn((n, self.y_dim), dtype=torch.float32).to(theta.device)
         y = gk_quantile(z, th[:, 0:1], th[:, 1:2], th[:, 2:3], th[:, 3:4], self.c)
         return torch.sort(y, dim=1).values
+
+    noise_dim = Y_DIM
+
+    def simulate_from_noise(self, theta, eps):
+        """generate_samples(theta, 1) with the y_dim standard normals supplied"""
+        if theta.is_cuda:
+            return _launch_simulate(self.descriptor(), theta, eps)
+        th = theta.reshape(-1, 4)
+        return torch.sort(gk_quantile(eps, th[:, 0:1], th[:, 1:2], th[:, 2:3], th[:, 3:4], self.c), dim=1).values
 
     def prior_log_prob(self, samples):
         samples = samples.view(-1, self.theta_dim)

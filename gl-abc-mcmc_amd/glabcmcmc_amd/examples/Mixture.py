@@ -12,7 +12,7 @@ import torch
 
 from .. import _capi
 from .. import distribution
-from ..distribution import _fill, _launch_rowwise
+from ..distribution import _fill, _launch_rowwise, _launch_simulate
 
 
 class Mixture_set:
@@ -45,6 +45,18 @@ class Mixture_set:
         dim_theta = theta.shape[1]
         noise = lik.sample(num_samples * num_theta).view(num_theta, num_samples, dim_theta).to(dev)
         return torch.abs(theta).unsqueeze(1).repeat(1, num_samples, 1) + noise
+
+    @property
+    def noise_dim(self):
+        """standard normals one simulation consumes (generic.py hands them over from the run's Philox stream)"""
+        return self.y_dim
+
+    def simulate_from_noise(self, theta, eps):
+        """generate_samples(theta, 1) with the simulator's standard normals supplied: |theta| + (loc + scale*eps)"""
+        if theta.is_cuda:
+            return _launch_simulate(self.descriptor(), theta, eps)
+        lik = self._likelihood()
+        return torch.abs(theta) + (lik.loc + torch.exp(lik.log_scale) * eps)
 
     def prior_log_prob(self, samples):
         samples = samples.view(-1, self.theta_dim)

@@ -1,0 +1,248 @@
+"""The sampler loops for Models that are plain Python objects (the reference's duck-typed Model protocol).
+
+The reference calls ``ABCset.generate_samples / prior_log_prob / calculate_log_kernel`` from inside its loops
+(GLMCMC.py:71-74,94-97; GlobalMCMC.py:41-46,57-61; protocol: examples/Mixture.py:5-53).  A Model that exposes
+``descriptor()`` is compiled into the fused gfx950 kernels; every other Model -- a user's own simulator -- runs here:
+one iteration for ALL chains is
+
+    glabc_propose            HIP: every random draw of the iteration (the fused kernels' Philox slots), candidates
+    Model callbacks          the user's code on one (batch_size * n_chains, dim) batch -- CUDA tensors, or CPU tensors
+                             for Models written against CPU tensors (``callback_device``)
+    [glabc_propose_redraw]   HIP: the prior-sentinel redraw loop of GLMCMC.py:92-93
+    glabc_select             HIP: iSIR weights / torch.sum order / double-precision index or the MH test, state update,
+                             Theta_Re row, ESJD and moment sums
+
+so the decisions are taken by the same arithmetic as in the fused kernels, and the Model is called
+``batch_size * n_chains`` rows at a time instead of ``batch_size`` rows.  Proposal objects without a ``glabc_dist``
+descriptor (``Gamma``, ``GaussianMixture``, a user's class) are callbacks too: ``forward`` / ``sample`` / ``log_prob``.
+
+Optional extension of the protocol: a Model with ``noise_dim`` and ``simulate_from_noise(theta, eps)`` receives the
+simulator's standard normals from the run's Philox stream (reproducible from ``seed``, independent of sharding); without
+it ``generate_samples(theta, 1)`` draws from whatever generator the Model uses.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _capi, _host, engine
+
+SENTINEL = float(np.float32(7 * math.log(1e-10)))           # GLMCMC.py:92
+
+
+def try_descriptor(obj):
+    """obj.descriptor() or None when the object cannot describe itself as a glabc_dist / glabc_model"""
+    fn = getattr(obj, "descriptor", None)
+    if fn is None:
+        return None
+    try:
+        return fn()
+    except (NotImplementedError, ValueError):
+        return None
+
+
+def dist_descriptor(obj, dim):
+    """the object's glabc_dist if it has one that a sampler can draw from (DiagGaussian / Uniform of the right dimension)"""
+    d = try_descriptor(obj)
+    if d is None or not isinstance(d, _capi.Dist):
+        return None                                          # e.g. Gamma (a glabc_gamma), GaussianMixture, a user's class
+    if d.dim != dim:
+        raise ValueError("proposal dimension %d does not match Model.theta_dim = %d" % (d.dim, dim))
+    return d
+
+
+def fused_supported(ABCset, proposals, batch_size):
+    """Can the fused kernels (glabc_glmcmc_steps / glabc_globalmcmc_steps / glabc_glmala_steps) run this configuration?"""
+    m = try_descriptor(ABCset)
+    if m is None or not isinstance(m, _capi.Model):
+        return False
+    for p in proposals:
+        d = try_descriptor(p)
+        if d is None or not isinstance(d, _capi.Dist) or d.dim != m.theta_dim:
+            return False
+    if m.sim_kind == _capi.SIM_ABS_GAUSS and not 1 <= m.theta_dim <= 4:
+        return False                                         # the fused kernels are instantiated for theta_dim 1..4
+    return batch_size is None or 1 <= int(batch_size) <= _capi.MAX_BATCH
+
+
+class ModelCallbacks:
+    """Evaluates a duck-typed Model on candidate batches, on the device its code can work with."""
+
+    def __init__(self, abc_set, device, callback_device="auto"):
+        self.m = abc_set
+        self.device = device
+        if callback_device not in ("auto", "cuda", "cpu"):
+            raise ValueError("callback_device must be 'auto', 'cuda' or 'cpu'")
+        self.auto = callback_device == "auto"
+        self.where = None if self.auto else callback_device
+        self.noise_dim = int(getattr(abc_set, "noise_dim", 0)) if hasattr(abc_set, "simulate_from_noise") else 0
+
+    def _to(self, t):
+        return t if self.where == "cuda" else t.cpu()
+
+    def _back(self, t, rows):
+        t = torch.as_tensor(t)
+        return t.detach().to(device=self.device, dtype=torch.float32).reshape(rows, -1).contiguous()
+
+    def _call(self, fn):
+        """fn(on_cuda: bool).  'auto': a Model written against CPU tensors (the reference's own examples/Mixture.py
+        mixes its CPU constants into the arithmetic) raises on CUDA tensors -- then, and from then on, it gets CPU copies."""
+        if self.auto and self.where != "cpu":
+            try:
+                out = fn(True)
+                self.where = "cuda"
+                return out
+            except (RuntimeError, TypeError, ValueError):
+                self.where = "cpu"
+        return fn(self.where == "cuda")
+
+    def prior(self, theta):
+        rows = theta.shape[0]
+        return self._call(lambda cuda: self._back(self.m.prior_log_prob(theta if cuda else theta.cpu()), rows)).view(-1)
+
+    def kernel(self, y):
+        rows = y.shape[0]
+        return self._call(lambda cuda: self._back(self.m.calculate_log_kernel(y if cuda else y.cpu()), rows)).view(-1)
+
+    def simulate(self, theta, noise):
+        rows = theta.shape[0]
+        if self.noise_dim:
+            return self._call(lambda cuda: self._back(
+                self.m.simulate_from_noise(theta if cuda else theta.cpu(), noise if cuda else noise.cpu()), rows))
+        return self._call(lambda cuda: self._back(self.m.generate_samples(theta if cuda else theta.cpu(), 1), rows))
+
+
+class ProposalCallbacks:
+    """A proposal object without a glabc_dist descriptor: forward / sample / log_prob as callbacks."""
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+
+    def _dev(self, t, rows):
+        return torch.as_tensor(t).detach().to(device=self.device, dtype=torch.float32).reshape(rows, -1).contiguous()
+
+    def forward(self, n):
+        z, lp = self.dist.forward(n)
+        return self._dev(z, n), self._dev(lp, n).view(-1)
+
+    def sample(self, n):
+        return self._dev(self.dist.sample(n), n)
+
+    def log_prob(self, theta):
+        try:
+            out = self.dist.log_prob(theta)
+        except (RuntimeError, TypeError, ValueError):
+            out = self.dist.log_prob(theta.cpu())
+        return self._dev(out, theta.shape[0]).view(-1)
+
+
+def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_Proposal, filelocation, global_frequency,
+        batch_size, csv_variant, *, seed=None, device=None, chain0=0, record_history=True, stats=None, return_device=False,
+        verbose=True, state_out=None, callback_device="auto", sentinel_redraw=True, max_redraws=100000, progress=None):
+    """GLMCMC (algo = _capi.ALGO_GLMCMC, GLMCMC.py:24-137) or GlobalMCMC (_capi.ALGO_GLOBALMCMC, GlobalMCMC.py:6-98) with
+    the Model -- and, if need be, the proposals -- as callbacks.  Same return value and side effects as the fused path."""
+    lib = _capi.lib()
+    dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
+    n, d, yd = chains.n, chains.d, chains.yd
+    N = int(batch_size) if algo == _capi.ALGO_GLMCMC else 1
+    if N < 1:
+        raise ValueError("batch_size must be >= 1")
+    key = engine.draw_seed(seed)
+    model = ModelCallbacks(ABCset, dev, callback_device)
+    local_desc = dist_descriptor(Local_Proposal, d) if Local_Proposal is not None else None
+    global_desc = dist_descriptor(Global_Proposal, d)
+    local_cb = ProposalCallbacks(Local_Proposal, dev) if (local_desc is None and Local_Proposal is not None) else None
+    global_cb = ProposalCallbacks(Global_Proposal, dev) if global_desc is None else None
+    if Local_Proposal is None and float(global_frequency) < 1:
+        raise ValueError("a local proposal is needed unless global_frequency >= 1")
+
+    R = N * n
+    f32 = dict(dtype=torch.float32, device=dev)
+    theta_prop = torch.zeros(R, d, **f32)
+    log_q = torch.zeros(R, **f32)
+    nd = model.noise_dim
+    sim_noise = torch.zeros(R, nd, **f32) if nd else None
+    log_u = torch.zeros(n, **f32)
+    u_res = torch.zeros(n, dtype=torch.float64, device=dev)
+    is_global = torch.zeros(n, dtype=torch.int32, device=dev)
+    n_redrawn = torch.zeros(1, dtype=torch.int32, device=dev)
+    # callbacks of the initial state (GLMCMC.py:52-55): carried from here on by glabc_select
+    prior_cur = model.prior(chains.theta.t().contiguous()).clone()
+    kern_cur = model.kernel(chains.y.t().contiguous()).clone()
+    hist = _host.allocate_history(num_ite, chains, record_history)
+
+    io = _capi.StepIO()
+    io.n_prop, io.theta_dim, io.y_dim, io.noise_dim = N, d, yd, nd
+    io.theta_prop, io.log_q = theta_prop.data_ptr(), log_q.data_ptr()
+    io.sim_noise = sim_noise.data_ptr() if nd else None
+    io.log_u, io.u_res, io.is_global = log_u.data_ptr(), u_res.data_ptr(), is_global.data_ptr()
+    io.prior_cur, io.kern_cur = prior_cur.data_ptr(), kern_cur.data_ptr()
+    cs = chains.struct()
+    ms = stats.struct() if stats is not None else None
+    run_ = _capi.Run()
+    run_.seed, run_.n_steps, run_.global_frequency, run_.batch_size, run_.hist_stride = key, 1, float(global_frequency), N, n
+    if ms is not None:
+        run_.moments = C.pointer(ms)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    hist_ptr, hist_row_bytes = (hist.data_ptr(), hist[0].numel() * 4) if hist is not None else (0, 0)
+    lp = C.byref(local_desc) if local_desc is not None else None
+    gp = C.byref(global_desc) if global_desc is not None else None
+    row0_local = None
+
+    with torch.cuda.device(dev):
+        for i in range(1, num_ite):
+            run_.step0 = i
+            run_.history = hist_ptr + i * hist_row_bytes if hist is not None else None
+            _capi.check(lib.glabc_propose(algo, lp, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_propose")
+            if global_cb is not None or local_cb is not None:
+                glob_rows = (is_global != 0)
+                if global_cb is not None:                                  # Importance_Proposal.forward(batch_size), GLMCMC.py:66
+                    z, lq = global_cb.forward(R)
+                    if local_cb is None:                                   # keep the kernel's local-move rows
+                        keep = torch.zeros(R, dtype=torch.bool, device=dev)
+                        keep[:n] = ~glob_rows
+                        z = torch.where(keep.view(-1, 1), theta_prop, z)
+                    theta_prop.copy_(z)
+                    log_q.copy_(lq)
+                if local_cb is not None:                                   # Local_Proposal.sample(1) + Theta_old, GLMCMC.py:91
+                    row0_local = local_cb.sample(n) + chains.theta.t()
+                    theta_prop[:n] = torch.where(glob_rows.view(-1, 1), theta_prop[:n], row0_local)
+            prior_prop = model.prior(theta_prop)                           # GLMCMC.py:74,92,96
+            io.prior_prop = prior_prop.data_ptr()
+            if sentinel_redraw and algo == _capi.ALGO_GLMCMC:              # GLMCMC.py:92-93
+                for rnd in range(1, max_redraws + 1):
+                    if local_cb is None:
+                        n_redrawn.zero_()
+                        _capi.check(lib.glabc_propose_redraw(lp, C.byref(cs), C.byref(run_), C.byref(io), rnd,
+                                                             n_redrawn.data_ptr(), stream), "glabc_propose_redraw")
+                        if int(n_redrawn.item()) == 0:
+                            break
+                        prior_prop[:n] = model.prior(theta_prop[:n])
+                    else:
+                        again = (is_global == 0) & (prior_prop[:n] == SENTINEL)
+                        k = int(again.sum().item())
+                        if k == 0:
+                            break
+                        theta_prop[:n][again] = local_cb.sample(k) + chains.theta.t()[again]
+                        prior_prop[:n] = model.prior(theta_prop[:n])
+                else:
+                    raise RuntimeError("the local proposal keeps landing where prior_log_prob returns the sentinel "
+                                       "7*log(1e-10) (GLMCMC.py:92-93) after %d redraws" % max_redraws)
+            y_prop = model.simulate(theta_prop, sim_noise)                 # GLMCMC.py:71,94
+            if y_prop.shape[1] != yd:
+                raise ValueError("generate_samples returned %d columns, Initial_y has %d" % (y_prop.shape[1], yd))
+            kern_prop = model.kernel(y_prop)                               # GLMCMC.py:72,96
+            io.y_prop, io.kern_prop = y_prop.data_ptr(), kern_prop.data_ptr()
+            q_cur = None
+            if global_cb is not None:                                      # Importance_Proposal.log_prob(Theta_old), GLMCMC.py:63
+                q_cur = global_cb.log_prob(chains.theta.t().contiguous())
+                io.q_cur = q_cur.data_ptr()
+            _capi.check(lib.glabc_select(algo, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_select")
+            if progress is not None:
+                progress(i)
+    if stats is not None:
+        stats.steps += num_ite - 1
+    if state_out is not None:
+        state_out.update(chains=chains, prior_cur=prior_cur, kern_cur=kern_cur, callback_device=model.where)
+    return _host.finish(hist, chains, single, filelocation, csv_variant, verbose and single, return_device)

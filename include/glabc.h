@@ -265,6 +265,74 @@ int glabc_glmcmc_nf_step(const glabc_model* model, const glabc_dist* local, cons
 int glabc_init_weights(const glabc_model* model, const glabc_dist* importance,
                        const glabc_chains* chains, void* stream);
 
+/* ---- split-phase iteration for Models whose callbacks are arbitrary code -------------------------------------------
+ * The reference's plug-in API is the duck-typed Model protocol (examples/Mixture.py:5-53): the sampler loops call
+ * ABCset.generate_samples / prior_log_prob / calculate_log_kernel (GLMCMC.py:71-74,94-97; GlobalMCMC.py:41-46,57-61).
+ * A Model that cannot describe itself as a glabc_model runs one iteration in three phases:
+ *
+ *   glabc_propose   every random draw of the iteration (same Philox slots as the fused kernels): the branch / accept /
+ *                   resampling numbers of each chain and its n_prop candidates theta' with their proposal log-density
+ *   the callbacks   generate_samples, prior_log_prob, calculate_log_kernel on the candidate rows -- PyTorch on the same
+ *                   device, or anything else that fills y_prop / prior_prop / kern_prop
+ *   glabc_select    iSIR weights, torch.sum normalisation, double-precision index (GLMCMC.py:74-88, 7-22) or the MH test
+ *                   (GLMCMC.py:96-103; GlobalMCMC.py:44-52,60-67), state update, Theta_Re row, streaming sums
+ *
+ * Candidate j of chain c is row r = j*n_chains + c of every candidate array (the Model sees one (n_prop*n_chains, dim)
+ * row-major batch).  A chain on the local branch uses row j = 0 only (theta' = Theta_old + increment, GLMCMC.py:91); its
+ * other rows still hold global candidates and are ignored by glabc_select.  All pointers are device pointers.
+ * theta_dim and y_dim are free in glabc_select (loops); a descriptor proposal limits theta_dim to GLABC_MAX_DIM. */
+typedef enum glabc_algo { GLABC_ALGO_GLMCMC = 0, GLABC_ALGO_GLOBALMCMC = 1 } glabc_algo;
+
+typedef struct glabc_step_io {
+    int32_t n_prop;                /* candidate rows per chain: batch_size (GLMCMC.py:66) | 1 (GlobalMCMC) */
+    int32_t theta_dim;
+    int32_t y_dim;
+    int32_t noise_dim;             /* standard normals per candidate handed to the simulator (0 = the Model draws its own) */
+    /* written by glabc_propose */
+    float* theta_prop;             /* [n_prop*n_chains][theta_dim] */
+    float* log_q;                  /* [n_prop*n_chains] forward()'s log_p of a global candidate (GLMCMC.py:66, GlobalMCMC.py:40) */
+    float* sim_noise;              /* NULL or [n_prop*n_chains][noise_dim]: words DP + i of the candidate's Philox blocks,
+                                      DP = theta_dim rounded up to even (the fused kernels' simulator draws) */
+    float* log_u;                  /* [n_chains] log(torch.rand(1)), GLMCMC.py:98 */
+    double* u_res;                 /* [n_chains] np.random.uniform(0,1), GLMCMC.py:17 */
+    int32_t* is_global;            /* [n_chains] torch.rand(1) < global_frequency, GLMCMC.py:59 */
+    /* written by the Model callbacks, read by glabc_select */
+    const float* y_prop;           /* [n_prop*n_chains][y_dim]  generate_samples(theta_prop, 1) */
+    const float* prior_prop;       /* [n_prop*n_chains]         prior_log_prob(theta_prop) */
+    const float* kern_prop;        /* [n_prop*n_chains]         calculate_log_kernel(y_prop) */
+    /* callbacks of the CURRENT state, carried from the iteration in which it was proposed (the reference re-evaluates
+     * them every iteration, GLMCMC.py:61-64,97; pure functions of the state) -- maintained by glabc_select */
+    float* prior_cur;              /* [n_chains] prior_log_prob(Theta_old) */
+    float* kern_cur;               /* [n_chains] calculate_log_kernel(y_old) */
+    const float* q_cur;            /* NULL (glabc_select evaluates the descriptor `global` at Theta_old) or [n_chains]
+                                      Importance_Proposal.log_prob(Theta_old) from the caller */
+} glabc_step_io;
+
+/* Philox slots of the local move's redraws (GLMCMC.py:92-93): round k of a chain reads blocks GLABC_SLOT_REDRAW + k*2 + b */
+#define GLABC_SLOT_REDRAW 0x40000000u
+
+/* Draws of iteration run->step0 for every chain (run->n_steps must be 1).  `local` / `global` may be NULL: the caller then
+ * fills the corresponding rows of theta_prop / log_q itself (proposal objects without a descriptor). */
+int glabc_propose(int algo, const glabc_dist* local, const glabc_dist* global, const glabc_chains* chains,
+                  const glabc_run* run, const glabc_step_io* io, void* stream);
+
+/* GLMCMC.py:92-93, `while prior_log_prob(Theta_prop) == 7*log(1e-10): redraw`: for every chain on the local branch whose
+ * prior_prop[c] equals the sentinel, row c of theta_prop <- Theta_old + a fresh increment (redraw round `round` >= 1) and
+ * n_redrawn (device counter, caller-zeroed) is incremented.  The caller re-evaluates prior_prop and repeats until 0. */
+int glabc_propose_redraw(const glabc_dist* local, const glabc_chains* chains, const glabc_run* run, const glabc_step_io* io,
+                         int32_t round, int32_t* n_redrawn, void* stream);
+
+/* The decision and the state update of iteration run->step0 (run->n_steps must be 1; run->history, if any, receives the
+ * Theta_Re row; run->moments the streaming sums).  chains->log_w / flags are required for GLABC_ALGO_GLMCMC. */
+int glabc_select(int algo, const glabc_dist* global, const glabc_chains* chains, const glabc_run* run,
+                 const glabc_step_io* io, void* stream);
+
+/* generate_samples(theta, 1) of a descriptor Model on n row-major points (Mixture.py:13-26 regime n x 1):
+ * theta[n][theta_dim], eps[n][y_dim] standard normals (NULL: drawn from Philox(seed; row0 + r, 0, b), pairs of words)
+ * -> y[n][y_dim].  The standalone form of the simulator the fused kernels inline. */
+int glabc_model_simulate(const glabc_model* model, const float* theta, const float* eps, int64_t n, uint64_t seed,
+                         int64_t row0, float* y, void* stream);
+
 /* distribution.py:176-181 / 81-86 / 123-137: log_prob of n row-major points z[n][dim] -> out[n]. */
 int glabc_dist_log_prob(const glabc_dist* dist, const float* z, int64_t n, float* out, void* stream);
 

@@ -39,17 +39,60 @@
 
 /* ------------------------------------------------------------------------- */
 /* ATen's float32 sum over a contiguous row of n elements, as this torch build
- * (2.10, CPU) associates it -- probed in the build container, see DESIGN.md
- * "row-sum order".  n < 8: four scalar lanes, leftovers into lane 0, lanes
- * combined left to right.  n >= 8: the same four-lane scheme over 8-wide
- * vectors, then a scalar accumulator takes the n%8 tail in order and finally
- * the 8 vector partials in order.  Matters because the reference normalises
- * the N+1 iSIR weights with torch.sum (GLMCMC.py:82). */
-static float aten_rowsum_f32(const float* x, int n)
+ * (2.10, CPU) associates it -- probed in the build container for n up to 20 000, see
+ * DESIGN.md "row-sum order"; aten/src/ATen/native/cpu/SumKernel.cpp is the published
+ * algorithm.  n < 8: four scalar lanes, leftovers into lane 0, lanes combined left to
+ * right.  n >= 8: 8-wide vectors dealt to four accumulators (row_sum, ilp_factor 4: the
+ * vectors of the full groups of four go to accumulator v % 4, leftover vectors to
+ * accumulator 0), each accumulator a four-level cascade (multi_row_sum: every 16 additions
+ * level 0 is folded into level 1, every 256 level 1 into level 2, ...), accumulators
+ * combined left to right, then a scalar accumulator takes the n%8 tail in order and finally
+ * the 8 vector partials in order.  Matters because the reference normalises the N+1 iSIR
+ * weights with torch.sum (GLMCMC.py:82). */
+static int ceil_log2_i64(int64_t x)                 /* c10 utils::CeilLog2 */
+{
+    if (x <= 2) return 1;
+    int b = 0;
+    for (uint64_t v = (uint64_t)(x - 1); v; v >>= 1) ++b;
+    return b;
+}
+
+/* multi_row_sum<float, 4>: rows = groups of four 8-wide vectors; result in out[4][8] */
+static void aten_multi_row_sum(const float* x, int64_t groups, float out[4][8])
+{
+    float acc[4][4][8];
+    memset(acc, 0, sizeof acc);
+    int64_t level_power = ceil_log2_i64(groups) / 4;
+    if (level_power < 4) level_power = 4;
+    const int64_t level_step = (int64_t)1 << level_power, level_mask = level_step - 1;
+    int64_t i = 0;
+    while (i + level_step <= groups) {
+        for (int64_t j = 0; j < level_step; ++j, ++i)
+            for (int q = 0; q < 4; ++q)
+                for (int k = 0; k < 8; ++k) acc[0][q][k] += x[8 * (4 * i + q) + k];
+        for (int j = 1; j < 4; ++j) {
+            for (int q = 0; q < 4; ++q)
+                for (int k = 0; k < 8; ++k) {
+                    acc[j][q][k] += acc[j - 1][q][k];
+                    acc[j - 1][q][k] = 0.0f;
+                }
+            if ((i & (level_mask << (j * level_power))) != 0) break;
+        }
+    }
+    for (; i < groups; ++i)
+        for (int q = 0; q < 4; ++q)
+            for (int k = 0; k < 8; ++k) acc[0][q][k] += x[8 * (4 * i + q) + k];
+    for (int j = 1; j < 4; ++j)
+        for (int q = 0; q < 4; ++q)
+            for (int k = 0; k < 8; ++k) acc[0][q][k] += acc[j][q][k];
+    memcpy(out, acc[0], sizeof acc[0]);
+}
+
+static float aten_rowsum_f32(const float* x, int64_t n)
 {
     if (n <= 0) return 0.0f;
     if (n < 8) {
-        int g = n / 4;
+        int g = (int)n / 4;
         if (g == 0) {
             float s = x[0];
             for (int i = 1; i < n; ++i) s = s + x[i];
@@ -59,33 +102,19 @@ static float aten_rowsum_f32(const float* x, int n)
         for (int i = 4; i < n; ++i) l0 = l0 + x[i];     /* g == 1 here: all leftovers go to lane 0 */
         return ((l0 + l1) + l2) + l3;
     }
-    int nv = n / 8;
-    float acc[8];
-    {
-        int g = nv / 4;
-        if (g == 0) {
-            for (int k = 0; k < 8; ++k) acc[k] = x[k];
-            for (int v = 1; v < nv; ++v)
-                for (int k = 0; k < 8; ++k) acc[k] = acc[k] + x[8 * v + k];
-        } else {
-            float l[4][8];
-            for (int q = 0; q < 4; ++q)
-                for (int k = 0; k < 8; ++k) l[q][k] = x[8 * q + k];
-            for (int i = 1; i < g; ++i)
-                for (int q = 0; q < 4; ++q)
-                    for (int k = 0; k < 8; ++k) l[q][k] = l[q][k] + x[8 * (4 * i + q) + k];
-            for (int v = 4 * g; v < nv; ++v)
-                for (int k = 0; k < 8; ++k) l[0][k] = l[0][k] + x[8 * v + k];
-            for (int k = 0; k < 8; ++k) acc[k] = ((l[0][k] + l[1][k]) + l[2][k]) + l[3][k];
-        }
-    }
+    int64_t nv = n / 8, g = nv / 4;
+    float l[4][8], acc[8];
+    aten_multi_row_sum(x, g, l);
+    for (int64_t v = 4 * g; v < nv; ++v)
+        for (int k = 0; k < 8; ++k) l[0][k] = l[0][k] + x[8 * v + k];
+    for (int k = 0; k < 8; ++k) acc[k] = ((l[0][k] + l[1][k]) + l[2][k]) + l[3][k];
     float fa = 0.0f;
-    for (int i = 8 * nv; i < n; ++i) fa = fa + x[i];
+    for (int64_t i = 8 * nv; i < n; ++i) fa = fa + x[i];
     for (int k = 0; k < 8; ++k) fa = fa + acc[k];
     return fa;
 }
 
-ORACLE_API float oracle_aten_rowsum_f32(const float* x, int n) { return aten_rowsum_f32(x, n); }
+ORACLE_API float oracle_aten_rowsum_f32(const float* x, int n) { return aten_rowsum_f32(x, (int64_t)n); }
 
 /* ------------------------------------------------------------------------- */
 /* distribution.py */
@@ -1505,4 +1534,192 @@ ORACLE_API void oracle_step_draws(uint64_t seed, uint64_t chain, uint32_t step, 
     *r = dr.u_resample;
     for (int j = 0; j < n_prop; ++j)
         for (int i = 0; i < d + yd; ++i) z[j * (d + yd) + i] = dr.z[j][i];
+}
+
+/* ========================================================================= */
+/* Split-phase iteration (include/glabc.h: glabc_propose / glabc_select): the  */
+/* same iteration of GLMCMC.py:58-104 / GlobalMCMC.py:37-68 cut where the loop  */
+/* calls the Model, so that the Model can be arbitrary code.                    */
+/* ========================================================================= */
+
+/* the draws of candidate j of (chain, step): e[d] proposal noise (normals, or [0,1) uniforms for a Uniform
+ * proposal), noise[nd] simulator normals from word dp = d rounded up to even */
+static void candidate_draws(uint64_t seed, uint64_t chain, uint32_t step, int j, int d, int nd, int uniform, float* e,
+                            float* noise)
+{
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), c0 = (uint32_t)chain, c1 = (uint32_t)(chain >> 32);
+    const int dp = d + (d & 1), spp = (dp + nd + 3) / 4;
+    for (int b = 0; b < spp; ++b) {
+        glabc_u32x4 o = glabc_philox4x32_10(c0, c1, step, (uint32_t)(1 + j * spp + b), k0, k1);
+        float nrm[4];
+        glabc_normal_pair(o.v[0], o.v[1], &nrm[0], &nrm[1]);
+        glabc_normal_pair(o.v[2], o.v[3], &nrm[2], &nrm[3]);
+        for (int t = 0; t < 4; ++t) {
+            int g = 4 * b + t;
+            if (g < d) e[g] = uniform ? glabc_uniform_f32(o.v[t]) : nrm[t];
+            if (noise && g >= dp && g - dp < nd) noise[g - dp] = nrm[t];
+        }
+    }
+}
+
+static int step_io_check(int algo, const glabc_chains* c, const glabc_run* r, const glabc_step_io* io)
+{
+    if (!c || !r || !io) return GLABC_ERR_NULL;
+    if (algo != GLABC_ALGO_GLMCMC && algo != GLABC_ALGO_GLOBALMCMC) return GLABC_ERR_KIND;
+    if (io->theta_dim < 1 || io->y_dim < 1 || io->noise_dim < 0) return GLABC_ERR_DIM;
+    if (io->n_prop < 1 || (algo == GLABC_ALGO_GLOBALMCMC && io->n_prop != 1)) return GLABC_ERR_ARG;
+    if (r->n_steps != 1 || r->tape) return GLABC_ERR_ARG;
+    if (!c->theta || !c->y) return GLABC_ERR_NULL;
+    return 0;
+}
+
+ORACLE_API int oracle_propose(int algo, const glabc_dist* local, const glabc_dist* global, const glabc_chains* c,
+                              const glabc_run* run, const glabc_step_io* io)
+{
+    int rc = step_io_check(algo, c, run, io);
+    if (rc) return rc;
+    const int d = io->theta_dim, nd = io->noise_dim, N = io->n_prop;
+    if ((local || global) && d > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    const int64_t C = c->n_chains;
+    for (int64_t i = 0; i < C; ++i) {
+        const uint64_t chain = (uint64_t)(c->chain0 + i);
+        glabc_u32x4 h = glabc_philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), run->step0, 0u, (uint32_t)run->seed,
+                                            (uint32_t)(run->seed >> 32));
+        const float gf = run->global_frequency_per_chain ? run->global_frequency_per_chain[i] : run->global_frequency;
+        const int is_global = glabc_uniform_f32(h.v[0]) < gf;                   /* GLMCMC.py:59 */
+        io->is_global[i] = is_global;
+        io->log_u[i] = glabc_logf(glabc_uniform_f32(h.v[1]));                   /* GLMCMC.py:98 */
+        io->u_res[i] = glabc_uniform_f64(h.v[2], h.v[3]);                       /* GLMCMC.py:17 */
+        for (int j = 0; j < N; ++j) {
+            const int64_t r = (int64_t)j * C + i;
+            const glabc_dist* g = (j == 0 && !is_global) ? local : global;
+            float e[GLABC_MAX_DIM] = {0}, z[GLABC_MAX_DIM], lq = 0.0f;
+            candidate_draws(run->seed, chain, run->step0, j, d, nd, g && g->kind == GLABC_DIST_UNIFORM, e,
+                            io->sim_noise ? io->sim_noise + r * nd : NULL);
+            if (!g) continue;                                                   /* the caller fills these rows */
+            rc = prop_forward(g, e, z, &lq);                                    /* GLMCMC.py:66 / :91 */
+            if (rc) return rc;
+            if (j == 0 && !is_global) {
+                for (int k = 0; k < d; ++k) z[k] = z[k] + c->theta[k * c->stride + i];    /* GLMCMC.py:91 */
+                lq = 0.0f;
+            }
+            memcpy(io->theta_prop + r * d, z, sizeof(float) * d);
+            io->log_q[r] = lq;
+        }
+    }
+    return 0;
+}
+
+/* GLMCMC.py:92-93 */
+ORACLE_API int oracle_propose_redraw(const glabc_dist* local, const glabc_chains* c, const glabc_run* run,
+                                     const glabc_step_io* io, int32_t round, int32_t* n_redrawn)
+{
+    int rc = step_io_check(GLABC_ALGO_GLMCMC, c, run, io);
+    if (rc) return rc;
+    if (!local || !n_redrawn) return GLABC_ERR_NULL;
+    const int d = io->theta_dim;
+    const float sentinel = (float)(7.0 * log(1e-10));
+    for (int64_t i = 0; i < c->n_chains; ++i) {
+        if (io->is_global[i] || io->prior_prop[i] != sentinel) continue;
+        const uint64_t chain = (uint64_t)(c->chain0 + i);
+        float e[GLABC_MAX_DIM], z[GLABC_MAX_DIM], lq;
+        for (int b = 0; b < 2; ++b) {
+            glabc_u32x4 o = glabc_philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), run->step0,
+                                                GLABC_SLOT_REDRAW + (uint32_t)(2 * round + b), (uint32_t)run->seed,
+                                                (uint32_t)(run->seed >> 32));
+            float nrm[4];
+            glabc_normal_pair(o.v[0], o.v[1], &nrm[0], &nrm[1]);
+            glabc_normal_pair(o.v[2], o.v[3], &nrm[2], &nrm[3]);
+            for (int t = 0; t < 4; ++t) e[4 * b + t] = local->kind == GLABC_DIST_UNIFORM ? glabc_uniform_f32(o.v[t]) : nrm[t];
+        }
+        prop_forward(local, e, z, &lq);
+        for (int k = 0; k < d; ++k) io->theta_prop[i * d + k] = z[k] + c->theta[k * c->stride + i];
+        *n_redrawn += 1;
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_select(int algo, const glabc_dist* global, const glabc_chains* c, const glabc_run* run,
+                             const glabc_step_io* io)
+{
+    int rc = step_io_check(algo, c, run, io);
+    if (rc) return rc;
+    if (!global && !io->q_cur) return GLABC_ERR_NULL;
+    if (algo == GLABC_ALGO_GLMCMC && (!c->log_w || !c->flags)) return GLABC_ERR_NULL;
+    const int d = io->theta_dim, yd = io->y_dim, N = io->n_prop;
+    const int64_t C = c->n_chains;
+    float* lw = (float*)malloc(sizeof(float) * (size_t)(N + 1));
+    float* w = (float*)malloc(sizeof(float) * (size_t)(N + 1));
+    float* th_old = (float*)malloc(sizeof(float) * (size_t)d);
+    if (!lw || !w || !th_old) { free(lw); free(w); free(th_old); return GLABC_ERR_ARG; }
+    for (int64_t i = 0; i < C; ++i) {
+        const int is_global = io->is_global[i];
+        const float prior_c = io->prior_cur[i], kern_c = io->kern_cur[i];
+        for (int k = 0; k < d; ++k) th_old[k] = c->theta[k * c->stride + i];
+        float q_state = 0.0f;
+        if (io->q_cur) q_state = io->q_cur[i];
+        else dist_log_prob(global, th_old, &q_state);
+        int ind = 0;
+        if (algo == GLABC_ALGO_GLMCMC && is_global) {
+            if (c->flags[i] & GLABC_FLAG_LOCAL) c->log_w[i] = (prior_c + kern_c) - q_state;       /* GLMCMC.py:60-64 */
+            c->flags[i] &= ~GLABC_FLAG_LOCAL;                                                     /* :65 */
+            lw[0] = c->log_w[i];
+            for (int j = 0; j < N; ++j) {
+                const int64_t r = (int64_t)j * C + i;
+                lw[j + 1] = (io->prior_prop[r] + io->kern_prop[r]) - io->log_q[r];                /* :74 */
+            }
+            for (int k = 0; k <= N; ++k) {
+                w[k] = glabc_expf(lw[k]);                                                         /* :78 */
+                if (isnan(w[k])) w[k] = 0.0f;                                                     /* :80-81 */
+            }
+            const float tot = aten_rowsum_f32(w, N + 1);                                          /* :82 */
+            double acc = 0.0;
+            ind = -1;
+            for (int k = 0; k <= N; ++k) {                                                        /* :17-22 */
+                acc += (double)(w[k] / tot);
+                if (io->u_res[i] < acc) { ind = k; break; }
+            }
+            if (ind < 0) ind = 0;                                                                 /* :84 */
+        } else {
+            const float pk = io->prior_prop[i] + io->kern_prop[i];
+            float log_acc;
+            if (algo == GLABC_ALGO_GLOBALMCMC && is_global)
+                log_acc = (((pk + q_state) - io->log_q[i]) - prior_c) - kern_c;                   /* GlobalMCMC.py:44-46 */
+            else
+                log_acc = (pk - prior_c) - kern_c;                                                /* GLMCMC.py:96-97 */
+            ind = io->log_u[i] < log_acc ? 1 : 0;
+        }
+        if (ind > 0) {
+            const int64_t r = (int64_t)(ind - 1) * C + i;
+            for (int k = 0; k < d; ++k) c->theta[k * c->stride + i] = io->theta_prop[r * d + k];
+            for (int k = 0; k < yd; ++k) c->y[k * c->stride + i] = io->y_prop[r * yd + k];
+            io->prior_cur[i] = io->prior_prop[r];
+            io->kern_cur[i] = io->kern_prop[r];
+            if (algo == GLABC_ALGO_GLMCMC) {
+                if (is_global) c->log_w[i] = lw[ind];                                             /* GLMCMC.py:86 */
+                else c->flags[i] |= GLABC_FLAG_LOCAL;                                             /* GLMCMC.py:100 */
+            }
+            if (c->n_moves) c->n_moves[i] += 1u;
+        }
+        /* Theta_Re row and streaming sums, any theta_dim */
+        if (run->history)
+            for (int k = 0; k < d; ++k) run->history[k * run->hist_stride + i] = c->theta[k * c->stride + i];
+        if (run->moments) {
+            const glabc_moments* m = run->moments;
+            int k = 0;
+            for (int a = 0; a < d; ++a) {
+                const float ta = c->theta[a * c->stride + i];
+                m->sum_theta[a * c->stride + i] += (double)ta;
+                for (int b = a; b < d; ++b, ++k) {
+                    const float tb = c->theta[b * c->stride + i];
+                    m->sum_outer[k * c->stride + i] += (double)ta * (double)tb;
+                    m->sum_jump[k * c->stride + i] += ((double)ta - (double)th_old[a]) * ((double)tb - (double)th_old[b]);
+                }
+            }
+        }
+    }
+    free(lw);
+    free(w);
+    free(th_old);
+    return 0;
 }

@@ -59,6 +59,9 @@ _SIG = {
     "oracle_sincos2pi_v": (None, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "oracle_normal_pair_v": (None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "oracle_uniforms_v": (None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oracle_propose": (C.c_int, [C.c_int, _P(A.Dist), _P(A.Dist), _P(A.Chains), _P(A.Run), _P(A.StepIO)]),
+    "oracle_propose_redraw": (C.c_int, [_P(A.Dist), _P(A.Chains), _P(A.Run), _P(A.StepIO), C.c_int32, C.c_void_p]),
+    "oracle_select": (C.c_int, [C.c_int, _P(A.Dist), _P(A.Chains), _P(A.Run), _P(A.StepIO)]),
     "oracle_step_draws": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -69,8 +72,9 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            subprocess.check_call(["make", "-C", ORACLE_DIR])
+        # always through make: a checker older than its source must not be what the tests trust (on the GPU box the
+        # prebuilt library travels with the snapshot and make finds it up to date)
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIG.items():
             fn = getattr(h, name)
@@ -96,8 +100,8 @@ class HostChains:
         y = np.asarray(y, np.float32)
         n = theta.shape[0]
         self.n = n
-        self.theta = np.ascontiguousarray(theta.T)            # [d][n]
-        self.y = np.ascontiguousarray(y.T)
+        self.theta = np.array(theta.T, dtype=np.float32, order="C", copy=True)      # [d][n]; never an alias of the caller's array
+        self.y = np.array(y.T, dtype=np.float32, order="C", copy=True)
         self.log_w = np.zeros(n, np.float32) if with_isir else None
         self.flags = np.full(n, A.FLAG_LOCAL, np.uint32) if with_isir else None
         self.n_moves = np.zeros(n, np.uint32)

@@ -1,0 +1,400 @@
+"""The split-phase path for Models given as callbacks (glabc_propose -> Model callbacks -> glabc_select; generic.py).
+
+CPU part (oracle only): the split-phase restatement in oracle/ -- the reference's iteration cut where the loop calls the
+Model -- reproduces the REFERENCE's golden chains bit for bit and equals the one-piece restatement.
+GPU part: a Model object with nothing but the reference's protocol (no descriptor()) runs through the HIP kernels and the
+Python loop of generic.py and visits the reference's chains bit for bit when its callbacks are the build's row-wise
+kernels; plain-torch Models (CUDA-tensor and CPU-tensor flavours) reach the analytic posterior; the prior-sentinel redraw
+of GLMCMC.py:92-93, callback proposals, free theta_dim / batch_size.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib
+from helpers import SAMPLER_GOLDENS, bits, descriptors, load_golden, make_dist
+from glabcmcmc_amd import _capi as A
+
+PHILOX_GOLDENS = [n for n in SAMPLER_GOLDENS if "philox" in n]
+ALGO = {"glmcmc": A.ALGO_GLMCMC, "globalmcmc": A.ALGO_GLOBALMCMC}
+SENTINEL = np.float32(7 * math.log(1e-10))
+
+
+# ----------------------------------------------------------------------------------------------- oracle, split-phase
+def oracle_split_phase(L, algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=0, moments=None, redraw_prior=None):
+    """T iterations of oracle_propose -> oracle_model_* callbacks -> oracle_select; returns (history [T][d][n], HostChains).
+    redraw_prior: optional numpy function theta(n,d) -> prior (n,) replacing the Model's prior (sentinel tests)."""
+    n, d = theta0.shape
+    yd, nd = y0.shape[1], y0.shape[1]
+    Np = N if algo == A.ALGO_GLMCMC else 1
+    R = Np * n
+    hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
+    cs = hc.struct()
+    buf = dict(theta_prop=np.zeros((R, d), np.float32), log_q=np.zeros(R, np.float32), sim_noise=np.zeros((R, nd), np.float32),
+               log_u=np.zeros(n, np.float32), u_res=np.zeros(n, np.float64), is_global=np.zeros(n, np.int32),
+               y_prop=np.zeros((R, yd), np.float32), prior_prop=np.zeros(R, np.float32), kern_prop=np.zeros(R, np.float32),
+               prior_cur=np.zeros(n, np.float32), kern_cur=np.zeros(n, np.float32))
+    io = A.StepIO(Np, d, yd, nd, *[buf[k].ctypes.data for k in ("theta_prop", "log_q", "sim_noise", "log_u", "u_res", "is_global",
+                                                                 "y_prop", "prior_prop", "kern_prop", "prior_cur", "kern_cur")], None)
+
+    def prior_of(theta_rows, out):
+        if redraw_prior is not None:
+            out[:] = redraw_prior(theta_rows)
+        else:
+            assert L.oracle_model_prior_log_prob(C.byref(model), theta_rows.ctypes.data, len(theta_rows), out.ctypes.data) == 0
+
+    th0 = np.ascontiguousarray(theta0, np.float32)
+    prior_of(th0, buf["prior_cur"])
+    yy0 = np.ascontiguousarray(y0, np.float32)
+    assert L.oracle_model_log_kernel(C.byref(model), yy0.ctypes.data, n, buf["kern_cur"].ctypes.data) == 0
+    hist = np.zeros((T, d, n), np.float32)
+    n_red = np.zeros(1, np.int32)
+    total_redraws = 0
+    for t in range(T):
+        row = hist[t]
+        run, keep = oracle_lib.make_run(seed=seed, step0=1 + t, n_steps=1, gf=gf, batch=Np, history=row, moments=moments)
+        assert L.oracle_propose(algo, C.byref(local), C.byref(glob), C.byref(cs), C.byref(run), C.byref(io)) == 0
+        prior_of(buf["theta_prop"], buf["prior_prop"])
+        if algo == A.ALGO_GLMCMC:
+            for rnd in range(1, 1000):
+                n_red[0] = 0
+                assert L.oracle_propose_redraw(C.byref(local), C.byref(cs), C.byref(run), C.byref(io), rnd, n_red.ctypes.data) == 0
+                if n_red[0] == 0:
+                    break
+                total_redraws += int(n_red[0])
+                prior_of(buf["theta_prop"][:n], buf["prior_prop"][:n])
+        assert L.oracle_model_simulate(C.byref(model), buf["theta_prop"].ctypes.data, buf["sim_noise"].ctypes.data, R,
+                                       buf["y_prop"].ctypes.data) == 0
+        assert L.oracle_model_log_kernel(C.byref(model), buf["y_prop"].ctypes.data, R, buf["kern_prop"].ctypes.data) == 0
+        assert L.oracle_select(algo, C.byref(glob), C.byref(cs), C.byref(run), C.byref(io)) == 0
+    hc.redraws = total_redraws
+    return hist, hc
+
+
+@pytest.mark.parametrize("name", PHILOX_GOLDENS)
+def test_oracle_split_phase_reproduces_reference_chains(oracle, name):
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, local, glob = descriptors(cfg, g)
+    C_ = min(g["theta0"].shape[0], 12)                       # the per-iteration Python loop is slow; a dozen chains pin it
+    T = min(cfg["T"], 400)
+    hist, _ = oracle_split_phase(oracle, ALGO[str(g["algo"])], model, local, glob, g["theta0"][:C_], g["y0"][:C_], T,
+                                 cfg["seed"], cfg["gf"], cfg["N"], chain0=cfg.get("chain0", 0))
+    got = np.concatenate([g["theta0"][None, :C_], hist.transpose(0, 2, 1)], axis=0)
+    same = bits(got) == bits(g["chains"][:T + 1, :C_])
+    assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
+
+
+@pytest.mark.parametrize("algo,N,d", [("glmcmc", 5, 2), ("glmcmc", 16, 3), ("glmcmc", 1, 1), ("globalmcmc", 1, 2), ("glmcmc", 7, 4)])
+def test_oracle_split_phase_equals_one_piece(oracle, algo, N, d):
+    """state, flags, log_w, move counts and streaming sums after T iterations: split-phase == one-piece restatement"""
+    from test_stream_independence import abs_gauss_model, proposals
+    L = oracle
+    rng = np.random.default_rng(7 + d + N)
+    n, T, seed, gf = 64, 120, 4242, 0.6
+    model = abs_gauss_model(d, 0.4)
+    lp, ip = proposals(d, "uniform" if N == 7 else "gauss")
+    theta0 = rng.standard_normal((n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236 * rng.standard_normal((n, d))).astype(np.float32)
+    mom_a, mom_b = oracle_lib.HostMoments(n, d), oracle_lib.HostMoments(n, d)
+    hist, hc = oracle_split_phase(L, ALGO[algo], model, lp, ip, theta0, y0, T, seed, gf, N, chain0=10 ** 10, moments=mom_a)
+    ref = oracle_lib.HostChains(theta0, y0, chain0=10 ** 10)
+    cs = ref.struct()
+    hh = np.zeros((T, d, n), np.float32)
+    run, keep = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh, moments=mom_b)
+    if algo == "glmcmc":
+        assert L.oracle_init_weights(C.byref(model), C.byref(ip), C.byref(cs)) == 0
+        assert L.oracle_glmcmc_steps(C.byref(model), C.byref(lp), C.byref(ip), C.byref(cs), C.byref(run)) == 0
+    else:
+        assert L.oracle_globalmcmc_steps(C.byref(model), C.byref(lp), C.byref(ip), C.byref(cs), C.byref(run)) == 0
+    assert np.array_equal(bits(hist), bits(hh))
+    assert np.array_equal(hc.n_moves, ref.n_moves) and hc.n_moves.sum() > 0
+    assert np.array_equal(bits(hc.y), bits(ref.y))
+    for a, b in ((mom_a.sum_theta, mom_b.sum_theta), (mom_a.sum_outer, mom_b.sum_outer), (mom_a.sum_jump, mom_b.sum_jump)):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    if algo == "glmcmc":
+        # log_weight_old is only defined where the reference would have computed it: chains whose `local` flag is clear
+        clear = (ref.flags & A.FLAG_LOCAL) == 0
+        assert np.array_equal(hc.flags & A.FLAG_LOCAL, ref.flags & A.FLAG_LOCAL)
+        assert np.array_equal(bits(hc.log_w[clear]), bits(ref.log_w[clear]))
+
+
+def box_prior(lo, hi):
+    """a hand-written Model prior in the reference's convention: the sentinel 7*log(1e-10) outside the support"""
+    def f(theta):
+        inside = np.all((theta >= lo) & (theta <= hi), axis=1)
+        return np.where(inside, np.float32(-1.25), SENTINEL).astype(np.float32)
+    return f
+
+
+def test_oracle_sentinel_redraw_keeps_local_proposals_inside_the_support(oracle):
+    from test_stream_independence import abs_gauss_model, proposals
+    rng = np.random.default_rng(3)
+    n, T, d = 256, 60, 2
+    model = abs_gauss_model(d, 0.5)
+    lp, ip = proposals(d, "uniform")
+    ip = make_dist(("uniform", [0.9, 0.9], [2.0, 2.0])).descriptor()          # global candidates always inside the box
+    theta0 = rng.uniform(1.0, 1.9, (n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236 * rng.standard_normal((n, d))).astype(np.float32)
+    hist, hc = oracle_split_phase(oracle, A.ALGO_GLMCMC, model, lp, ip, theta0, y0, T, 5, 0.3, 3,
+                                  redraw_prior=box_prior(0.9, 2.0))
+    assert hc.redraws > 50                                   # sd-0.4 increments near a box edge do land outside
+    assert hist.min() >= 0.9 and hist.max() <= 2.0           # ... and none of them was ever simulated or accepted
+    assert hc.n_moves.sum() > 100
+
+
+# ----------------------------------------------------------------------------------------------------- GPU
+class FixedDescriptor:
+    """a proposal object whose glabc_dist is the fixture's (constants of the machine that ran the reference)"""
+
+    def __init__(self, desc):
+        self._d = desc
+
+    def descriptor(self):
+        return self._d
+
+
+class ProtocolModel:
+    """Nothing but the reference's Model protocol (examples/Mixture.py:5-53) plus the optional Philox-noise hook; the
+    callbacks are the build's row-wise HIP kernels for a fixed glabc_model.  Deliberately NO descriptor()."""
+
+    def __init__(self, desc, noise_hook=True):
+        self._m = desc
+        self.theta_dim, self.y_dim, self.epsilon = desc.theta_dim, desc.y_dim, desc.epsilon
+        self.y_obs = torch.tensor([list(desc.y_obs)[:desc.y_dim]])
+        if noise_hook:
+            self.noise_dim = desc.y_dim
+            self.simulate_from_noise = self._simulate_from_noise
+
+    def _simulate_from_noise(self, theta, eps):
+        from glabcmcmc_amd.distribution import _launch_simulate
+        return _launch_simulate(self._m, theta, eps)
+
+    def generate_samples(self, theta, num_samples=1):
+        theta = theta.reshape(-1, self.theta_dim)
+        return self._simulate_from_noise(theta, torch.randn(theta.shape[0], self.y_dim, device=theta.device))
+
+    def prior_log_prob(self, samples):
+        from glabcmcmc_amd.distribution import _launch_rowwise
+        return _launch_rowwise("glabc_model_prior_log_prob", self._m, samples.reshape(-1, self.theta_dim), "prior")
+
+    def discrepancy(self, y):
+        from glabcmcmc_amd.distribution import _launch_rowwise
+        return _launch_rowwise("glabc_model_discrepancy", self._m, y.reshape(-1, self.y_dim), "discrepancy")
+
+    def calculate_log_kernel(self, y, epsilon=None):
+        from glabcmcmc_amd.distribution import _launch_rowwise
+        return _launch_rowwise("glabc_model_log_kernel", self._m, y.reshape(-1, self.y_dim), "log_kernel")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PHILOX_GOLDENS)
+def test_hip_protocol_only_model_reproduces_reference_chains(hip, name):
+    """VERDICT r1 'done' criterion: a Model class with only the reference protocol runs run_glmcmc / run_global_mcmc and,
+    its callbacks being the build's row-wise kernels, walks the reference's golden chains bit for bit."""
+    import glabcmcmc_amd as g_
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, local, glob = descriptors(cfg, g)
+    pm = ProtocolModel(model)
+    assert not hasattr(pm, "descriptor")
+    T = min(cfg["T"], 500)
+    runner = g_.MCMCRunner(pm)
+    th0, y0 = torch.from_numpy(g["theta0"]), torch.from_numpy(g["y0"])
+    kw = dict(seed=cfg["seed"], chain0=cfg.get("chain0", 0), output_file=None, verbose=False)
+    if str(g["algo"]) == "glmcmc":
+        out = runner.run_glmcmc(T + 1, th0, y0, cfg["gf"], FixedDescriptor(local), FixedDescriptor(glob), cfg["N"], **kw)
+    else:
+        out = runner.run_global_mcmc(T + 1, th0, y0, cfg["gf"], FixedDescriptor(local), FixedDescriptor(glob), **kw)
+    got = out.numpy()
+    if got.ndim == 2:
+        got = got[:, None, :]
+    same = bits(got) == bits(g["chains"][:T + 1])
+    assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
+
+
+@pytest.mark.gpu
+def test_hip_generic_equals_fused_at_full_size(hip):
+    """65 536 chains: generic path (forced on the build's own Mixture_set) == fused kernel, histories and sums, bit for bit"""
+    from glabcmcmc_amd import GLMCMC, distribution, engine
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    n, T, seed = 65536, 12, 77
+    m = Mixture_set(0.05)
+    lp = distribution.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35])))
+    ip = distribution.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0]))
+    g = torch.Generator().manual_seed(5)
+    th0 = torch.randn(n, 2, generator=g)
+    y0 = th0.abs() + 0.2236 * torch.randn(n, 2, generator=g)
+    dev = torch.device("cuda", 0)
+    outs = []
+    for path in ("fused", "generic"):
+        mom = engine.Moments(n, 2, dev)
+        st = {}
+        h = GLMCMC(m, T + 1, th0, y0, lp, None, 0.9, ip, 5, seed=seed, stats=mom, return_device=True, verbose=False, path=path,
+                   state_out=st)
+        outs.append((h.cpu().numpy(), mom.sum_jump.cpu().numpy(), mom.sum_outer.cpu().numpy(), st["chains"].n_moves.cpu().numpy()))
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0]))
+    for k in (1, 2):
+        assert np.array_equal(outs[0][k].view(np.uint64), outs[1][k].view(np.uint64))
+    assert np.array_equal(outs[0][3], outs[1][3]) and outs[0][3].sum() > 1000
+
+
+class TorchMixture:
+    """A user's Model in plain torch, written for whatever device its inputs are on (d dimensions of examples/Mixture.py)"""
+
+    def __init__(self, d, epsilon):
+        self.theta_dim = self.y_dim = d
+        self.epsilon = epsilon
+        self.y_obs = torch.full((1, d), 1.5)
+
+    def generate_samples(self, theta, num_samples=1):
+        return theta.abs() + math.sqrt(0.05) * torch.randn_like(theta)
+
+    def prior_log_prob(self, samples):
+        return -0.5 * self.theta_dim * math.log(2 * math.pi) - 0.5 * (samples ** 2).sum(1)
+
+    def discrepancy(self, y):
+        return ((y - self.y_obs.to(y.device)) ** 2).sum(1).sqrt()
+
+    def calculate_log_kernel(self, y, epsilon=None):
+        e = self.discrepancy(y) / self.epsilon
+        return -0.5 * math.log(2 * math.pi) - math.log(self.epsilon) - 0.5 * e * e
+
+
+class CpuOnlyMixture(TorchMixture):
+    """The same Model written the way the reference's example is: CPU constants mixed into the arithmetic
+    (examples/Mixture.py:9,36) -- it raises on CUDA tensors, so the loop must hand it CPU copies."""
+
+    def discrepancy(self, y):
+        return ((y - self.y_obs) ** 2).sum(1).sqrt()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,d,N,n", [(TorchMixture, 2, 5, 65536), (TorchMixture, 6, 40, 4096), (CpuOnlyMixture, 2, 5, 8192)])
+def test_hip_plain_torch_model_reaches_analytic_moments(hip, cls, d, N, n):
+    """north_star: posterior moments within 1e-3 -- a user Model in plain torch at 65 536 chains; theta_dim 6 and
+    batch_size 40 are beyond anything the fused kernels are compiled for"""
+    from glabcmcmc_amd import GLMCMC, distribution, engine
+    from test_stream_independence import analytic
+    eps = 0.3
+    m = cls(d, eps)
+    lp = distribution.DiagGaussian(d, torch.zeros(d), torch.log(torch.full((d,), 0.3)))
+    ip = distribution.DiagGaussian(d, torch.zeros(d), torch.log(torch.full((d,), 1.4)))
+    g = torch.Generator().manual_seed(1)
+    th0 = 1.3 * (torch.randint(0, 2, (n, d), generator=g).float() * 2 - 1)
+    y0 = th0.abs() + 0.2236 * torch.randn(n, d, generator=g)
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    burn, T = 150, 400
+    st = {}
+    GLMCMC(m, burn + 1, th0, y0, lp, None, 0.6, ip, N, seed=3, record_history=False, verbose=False, state_out=st)
+    ch = st["chains"]
+    assert st["callback_device"] == ("cpu" if cls is CpuOnlyMixture else "cuda")
+    mom = engine.Moments(n, d, dev)
+    GLMCMC(m, T + 1, ch.theta.t().cpu(), ch.y.t().cpu(), lp, None, 0.6, ip, N, seed=4, record_history=False, stats=mom,
+           verbose=False)
+    _, want_sq = analytic(eps)
+    so = mom.sum_outer.cpu().numpy()
+    k = 0
+    for a in range(d):
+        per_chain = so[k] / T
+        se = per_chain.std(ddof=1) / np.sqrt(n)
+        assert abs(per_chain.mean() - want_sq) < 5 * se + 1e-3 * want_sq, (a, per_chain.mean(), want_sq, se)
+        k += d - a
+
+
+class BoxedModel(ProtocolModel):
+    """hand-written prior in the reference's sentinel convention (GLMCMC.py:92-93)"""
+
+    def prior_log_prob(self, samples):
+        s = samples.reshape(-1, self.theta_dim)
+        inside = ((s >= 0.9) & (s <= 2.0)).all(1)
+        return torch.where(inside, torch.full_like(s[:, 0], -1.25), torch.full_like(s[:, 0], float(SENTINEL)))
+
+
+@pytest.mark.gpu
+def test_hip_sentinel_redraw_equals_the_oracle(hip, oracle):
+    from glabcmcmc_amd import GLMCMC
+    from test_stream_independence import abs_gauss_model, proposals
+    rng = np.random.default_rng(3)
+    n, T, d = 256, 60, 2
+    model = abs_gauss_model(d, 0.5)
+    lp, _ = proposals(d, "uniform")
+    ip = make_dist(("uniform", [0.9, 0.9], [2.0, 2.0])).descriptor()
+    theta0 = rng.uniform(1.0, 1.9, (n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236 * rng.standard_normal((n, d))).astype(np.float32)
+    want, hc = oracle_split_phase(oracle, A.ALGO_GLMCMC, model, lp, ip, theta0, y0, T, 5, 0.3, 3, redraw_prior=box_prior(0.9, 2.0))
+    out = GLMCMC(BoxedModel(model), T + 1, torch.from_numpy(theta0), torch.from_numpy(y0), FixedDescriptor(lp), None, 0.3,
+                 FixedDescriptor(ip), 3, seed=5, verbose=False)
+    got = out.numpy()[1:].transpose(0, 2, 1)
+    assert hc.redraws > 50
+    assert np.array_equal(bits(got), bits(want))
+    off = GLMCMC(BoxedModel(model), T + 1, torch.from_numpy(theta0), torch.from_numpy(y0), FixedDescriptor(lp), None, 0.3,
+                 FixedDescriptor(ip), 3, seed=5, verbose=False, sentinel_redraw=False)
+    assert not np.array_equal(bits(off.numpy()[1:].transpose(0, 2, 1)), bits(want))       # the loop is what made them equal
+
+
+class MyProposal:
+    """a user's proposal class: no descriptor, torch's generator"""
+
+    def __init__(self, d, scale):
+        self.d, self.scale = d, scale
+
+    def forward(self, n):
+        eps = torch.randn(n, self.d)
+        return self.scale * eps, self.log_prob(self.scale * eps)
+
+    def sample(self, n):
+        return self.forward(n)[0]
+
+    def log_prob(self, z):
+        e = z / self.scale
+        return -0.5 * self.d * math.log(2 * math.pi) - self.d * math.log(self.scale) - 0.5 * (e * e).sum(1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["glmcmc", "globalmcmc"])
+def test_hip_callback_proposals(hip, algo):
+    """proposal objects without a descriptor (a user's class; Gamma) are callbacks: forward / sample / log_prob"""
+    from glabcmcmc_amd import GLMCMC, GlobalMCMC, distribution, engine
+    from test_stream_independence import analytic
+    d, n, eps, T = 2, 16384, 0.3, 500
+    m = TorchMixture(d, eps)
+    g = torch.Generator().manual_seed(1)
+    th0 = 1.3 * (torch.randint(0, 2, (n, d), generator=g).float() * 2 - 1)
+    y0 = th0.abs() + 0.2236 * torch.randn(n, d, generator=g)
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    mom = engine.Moments(n, d, dev)
+    lp, ip = MyProposal(d, 0.3), MyProposal(d, 1.4)
+    if algo == "glmcmc":
+        GLMCMC(m, T + 1, th0, y0, lp, None, 0.6, ip, 4, seed=3, record_history=False, stats=mom, verbose=False)
+    else:
+        GlobalMCMC(m, T + 1, th0, y0, ip, None, 0.5, lp, seed=3, record_history=False, stats=mom, verbose=False)
+    _, want_sq = analytic(eps)
+    per_chain = mom.sum_outer[0].cpu().numpy() / T
+    se = per_chain.std(ddof=1) / np.sqrt(n)
+    assert abs(per_chain.mean() - want_sq) < 5 * se + 2e-3 * want_sq, (per_chain.mean(), want_sq, se)
+
+
+def test_dispatch_without_a_device():
+    """no GPU here: a descriptor-less Model no longer raises TypeError -- it reaches the generic path, which (like the
+    fused one) refuses to run without a HIP device; path='fused' keeps the loud refusal"""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import generic
+    if torch.cuda.is_available():
+        pytest.skip("checks the CPU-only behaviour")
+    m = TorchMixture(2, 0.3)
+    dg = g_.DiagGaussian(2, torch.zeros(2), torch.zeros(2))
+    assert not generic.fused_supported(m, (dg, dg), 5)
+    assert generic.fused_supported(g_.examples.Mixture.Mixture_set(0.05), (dg, dg), 5) if hasattr(g_, "examples") else True
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        g_.GLMCMC(m, 10, torch.zeros(2), torch.zeros(1, 2), dg, None, 0.5, dg, 5)
+    with pytest.raises(TypeError, match="descriptor"):
+        g_.GLMCMC(m, 10, torch.zeros(2), torch.zeros(1, 2), dg, None, 0.5, dg, 5, path="fused")
+    ga = g_.Gamma(torch.tensor([2.0, 3.0]), torch.tensor([1.0, 2.0]))
+    assert generic.dist_descriptor(ga, 2) is None and generic.dist_descriptor(dg, 2) is not None
+    assert not generic.fused_supported(g_.examples.Mixture.Mixture_set(0.05), (dg, dg), 17)
