@@ -22,16 +22,31 @@ def shard_range(n_total, rank, world):
     return chain0, n_local
 
 
-def gather_rows(local_rows, world):
-    """All-gather equally-sized per-rank blocks [k][n] (chain-major) into [k][world*n],
-    ranks in order, i.e. in global chain-id order.  Works on any backend (gloo on CPU
-    tensors in the tests, nccl = RCCL on device tensors in production)."""
+def gather_rows(local_rows, world, return_counts=False):
+    """All-gather per-rank blocks [k][n_r] (chain-major) into [k][sum n_r], ranks in order, i.e. in global chain-id
+    order.  Shards may be ragged (shard_range hands the remainder of n_total % world to the low ranks): the block
+    widths are exchanged first (world int64 words), every block is padded to the widest, one all-gather moves the
+    payload, the padding is cut away.  Works on any backend (gloo on CPU tensors in the tests, nccl = RCCL on device
+    tensors in production)."""
     if world == 1:
-        return local_rows
+        return (local_rows, [local_rows.shape[1]]) if return_counts else local_rows
     k, n = local_rows.shape
-    out = torch.empty(world * k, n, dtype=local_rows.dtype, device=local_rows.device)
-    dist.all_gather_into_tensor(out, local_rows.contiguous())
-    return out.view(world, k, n).permute(1, 0, 2).reshape(k, world * n).contiguous()
+    mine = torch.tensor([n], dtype=torch.int64, device=local_rows.device)
+    widths = torch.empty(world, dtype=torch.int64, device=local_rows.device)
+    dist.all_gather_into_tensor(widths, mine)
+    counts = [int(v) for v in widths.tolist()]
+    n_max = max(counts)
+    block = local_rows.contiguous()
+    if n < n_max:
+        block = torch.cat([block, block.new_zeros(k, n_max - n)], dim=1)
+    out = torch.empty(world * k, n_max, dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(out, block)
+    out = out.view(world, k, n_max)
+    if min(counts) == n_max:
+        rows = out.permute(1, 0, 2).reshape(k, world * n_max).contiguous()
+    else:
+        rows = torch.cat([out[r, :, :counts[r]] for r in range(world)], dim=1).contiguous()
+    return (rows, counts) if return_counts else rows
 
 
 def gather_moments(mom, world, via=None):
@@ -44,11 +59,12 @@ def gather_moments(mom, world, via=None):
     packed = torch.cat([mom.sum_theta, mom.sum_outer, mom.sum_jump], dim=0)        # [d + 2 tri][n]
     home = packed.device
     if via is not None and torch.device(via) != home:
-        allrows = gather_rows(packed.to(via), world).to(home)
+        allrows, counts = gather_rows(packed.to(via), world, return_counts=True)
+        allrows = allrows.to(home)
     else:
-        allrows = gather_rows(packed, world)
+        allrows, counts = gather_rows(packed, world, return_counts=True)
     out = engine.Moments.__new__(engine.Moments)
-    out.n, out.d, out.steps = mom.n * world, d, mom.steps
+    out.n, out.d, out.steps = sum(counts), d, mom.steps
     out.sum_theta = allrows[:d].contiguous()
     out.sum_outer = allrows[d:d + tri].contiguous()
     out.sum_jump = allrows[d + tri:].contiguous()

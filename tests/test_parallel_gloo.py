@@ -35,8 +35,12 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-def test_gather_in_chain_id_order():
-    world, n_total = 2, 64
+import pytest
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 64), (2, 65), (3, 65), (3, 2)])
+def test_gather_in_chain_id_order(world, n_total):
+    """equal shards, ragged shards (65 chains over 2 and 3 ranks) and a rank with nothing to contribute"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -48,7 +52,8 @@ def test_gather_in_chain_id_order():
         p.join(60)
         assert p.exitcode == 0
     ids = torch.arange(n_total, dtype=torch.float64)
-    assert [(r[1], r[2]) for r in res] == [(0, 32), (32, 32)]
+    from glabcmcmc_amd.parallel import shard_range
+    assert [(r[1], r[2]) for r in res] == [shard_range(n_total, r, world) for r in range(world)]
     for r in res:
         assert torch.equal(r[3], torch.stack([ids, ids * 10 + 1, -ids]))
         assert r[4] == n_total and r[5] == 7
