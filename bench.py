@@ -170,6 +170,99 @@ def bench_kde(args):
                                            "construction (~60 vector instructions per pair over two passes); see DESIGN.md 4.3"}}), flush=True)
 
 
+def bench_callback(args):
+    """SURVEY.md 8b-ii, the reference's plug-in API: GLMCMC (iSIR N=5, gf 0.9) with a user Model that is a plain-torch
+    object -- no descriptor, so every iteration is glabc_propose -> the Model's callbacks on a (5 * chains, 2) batch ->
+    glabc_select (generic.py).  One step = --iters iterations of all chains."""
+    from glabcmcmc_amd import GLMCMC, _capi, distribution, engine
+    from glabcmcmc_amd.examples.UserModel import TorchMixture
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    n, K, N = args.chains, min(args.iters, 200), NBATCH
+    model = TorchMixture(2, EPS)
+    lp = distribution.DiagGaussian(2, torch.zeros(2), torch.log(torch.tensor([0.35, 0.35])))
+    ip = distribution.DiagGaussian(2, torch.zeros(2), torch.zeros(2))
+    torch.manual_seed(0)
+    state = {"theta": torch.zeros(n, 2), "y": (0.05 ** 0.5) * torch.randn(n, 2)}
+    mom = engine.Moments(n, 2, dev)
+    step_idx = [0]
+
+    def one_step():
+        st = {}
+        GLMCMC(model, K + 1, state["theta"], state["y"], lp, None, GF, ip, N, seed=20261003 + step_idx[0], record_history=False,
+               stats=mom, verbose=False, state_out=st, sentinel_redraw=not args.no_sentinel)
+        ch = st["chains"]
+        state["theta"], state["y"] = ch.theta.t(), ch.y.t()            # stay on the device (prepare() copies through the host)
+        step_idx[0] += 1
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    # the two HIP kernels of an iteration, timed on their own (HIP events on the launch stream, 100 launches each)
+    lib = _capi.lib()
+    R = N * n
+    f32 = dict(dtype=torch.float32, device=dev)
+    buf = dict(theta_prop=torch.zeros(R, 2, **f32), log_q=torch.zeros(R, **f32), log_u=torch.zeros(n, **f32),
+               u_res=torch.zeros(n, dtype=torch.float64, device=dev), is_global=torch.zeros(n, dtype=torch.int32, device=dev),
+               y_prop=torch.randn(R, 2, **f32), prior_prop=-torch.rand(R, **f32), kern_prop=-torch.rand(R, **f32),
+               prior_cur=-torch.rand(n, **f32), kern_cur=-torch.rand(n, **f32))
+    io = _capi.StepIO(N, 2, 2, 0, buf["theta_prop"].data_ptr(), buf["log_q"].data_ptr(), None, buf["log_u"].data_ptr(),
+                      buf["u_res"].data_ptr(), buf["is_global"].data_ptr(), buf["y_prop"].data_ptr(), buf["prior_prop"].data_ptr(),
+                      buf["kern_prop"].data_ptr(), buf["prior_cur"].data_ptr(), buf["kern_cur"].data_ptr(), None)
+    chains = engine.ChainBatch(torch.zeros(n, 2), torch.zeros(n, 2), dev)
+    cs, ms = chains.struct(), mom.struct()
+    hist = torch.zeros(2, n, **f32)
+    run = _capi.Run()
+    run.seed, run.step0, run.n_steps, run.global_frequency, run.batch_size = 1, 1, 1, GF, N
+    run.history, run.hist_stride, run.moments = hist.data_ptr(), n, C.pointer(ms)
+    lpd, ipd = lp.descriptor(), ip.descriptor()
+
+    def timed(fn, reps=100):
+        for _ in range(5):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ms_prop = timed(lambda: _capi.check(lib.glabc_propose(0, C.byref(lpd), C.byref(ipd), C.byref(cs), C.byref(run), C.byref(io),
+                                                          stream), "glabc_propose"))
+    ms_sel = timed(lambda: _capi.check(lib.glabc_select(0, C.byref(ipd), C.byref(cs), C.byref(run), C.byref(io), stream),
+                                       "glabc_select"))
+    bytes_prop = 4.0 * R * (2 + 1) + n * (4 + 8 + 4) + 4.0 * n * 2
+    bytes_sel = 4.0 * R * 3 + n * (4 + 8 + 4) + n * (8 + 16) + 4.0 * n * 2 + 2 * 8.0 * 8 * n
+    achieved = (bytes_prop + bytes_sel) / ((ms_prop + ms_sel) * 1e-3) / 1e9
+    esjd = mom.esjd()
+    ok = torch.isfinite(esjd)
+    out = {"metric": "MH accept-steps/sec, user Model as torch callbacks (split-phase path), 65 536 chains, dim=2",
+           "value": float(n) * K * args.steps / elapsed, "unit": "chain-steps/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "GLMCMC iSIR N=5 gf=0.9, examples/UserModel.TorchMixture (plain torch, no descriptor) eps=0.05 "
+                                  "d=2: glabc_propose -> callbacks -> glabc_select per iteration", "chains_per_gpu": n,
+                      "iters_per_step": K, "batch_size": N, "sentinel_redraw": not args.no_sentinel},
+           "us_per_iteration": elapsed / (args.steps * K) * 1e6,
+           "esjd_mean": float(esjd[ok].double().mean()),
+           "mean_theta_sq": float(mom.second_moment().diagonal(dim1=1, dim2=2).mean()), "analytic_mean_theta_sq": 2.081014,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "glabc::propose_kernel + glabc::select_kernel",
+                        "kernel_ms": ms_prop + ms_sel, "propose_ms": ms_prop, "select_ms": ms_sel,
+                        "algorithmic_bytes_per_launch": bytes_prop + bytes_sel,
+                        "note": "the two HIP kernels take %.0f us of the %.0f us of an iteration; the rest is the Model's "
+                                "~10 torch kernels and launch latency" % ((ms_prop + ms_sel) * 1e3, elapsed / (args.steps * K) * 1e6)}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,10 +274,12 @@ def main():
     ap.add_argument("--no-history", action="store_true", help="diagnostic: do not write Theta_Re rows")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default; geometry only)")
     ap.add_argument("--couplings", type=int, default=8, help="nf workload: number of couplings")
+    ap.add_argument("--no-sentinel", action="store_true", help="callback workload: skip the GLMCMC.py:92-93 redraw check "
+                    "(one device->host sync per iteration)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the multi-rank control flow on ONE GPU: every rank uses cuda:0 and the collectives "
                          "run on gloo with CPU copies (numbers are meaningless; RCCL needs one GPU per rank)")
-    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde"],
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
@@ -192,6 +287,8 @@ def main():
         return bench_nf(args)
     if args.workload == "kde":
         return bench_kde(args)
+    if args.workload == "callback":
+        return bench_callback(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) redraw_kernel(const GenArgs a)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= a.n_chains) return;
-    if (a.is_global[c]) return;
+    if (a.is_global[c] & 1) return;
     // the reference compares a float32 tensor with the Python float 7*log(1e-10): torch promotes the double to float32
     if (a.prior_prop[c] != (float)(7.0 * -23.025850929940457)) return;
     const uint64_t gid = (uint64_t)(a.chain0 + c);
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) select_kernel(const GenArgs a)
     if (c >= a.n_chains) return;
     const int D = a.theta_dim, YD = a.y_dim, N = a.n_prop;
     const int64_t C = a.n_chains;
-    const bool is_global = a.is_global[c] != 0;
+    const bool is_global = (a.is_global[c] & 1) != 0;
     const float prior_c = a.prior_cur[c], kern_c = a.kern_cur[c];
     uint32_t flags = a.flags ? a.flags[c] : 0u;
     float log_w = a.log_w ? a.log_w[c] : 0.0f;
@@ -307,7 +307,8 @@ __global__ void __launch_bounds__(256) select_kernel(const GenArgs a)
     };
 
     int ind = 0;
-    if (a.algo == GLABC_ALGO_GLMCMC && is_global) {
+    const bool isir = a.algo == GLABC_ALGO_GLMCMC || a.algo == GLABC_ALGO_GLMALA;
+    if (isir && is_global) {
         if (flags & GLABC_FLAG_LOCAL) log_w = (prior_c + kern_c) - q_of_state();          // GLMCMC.py:60-64
         flags &= ~GLABC_FLAG_LOCAL;                                                       // GLMCMC.py:65
         auto weight = [&](int k) -> float {                                               // GLMCMC.py:74-81
@@ -334,6 +335,8 @@ __global__ void __launch_bounds__(256) select_kernel(const GenArgs a)
         float log_acc;
         if (a.algo == GLABC_ALGO_GLOBALMCMC && is_global)
             log_acc = (((pk + q_of_state()) - a.log_q[c]) - prior_c) - kern_c;            // GlobalMCMC.py:44-46
+        else if (a.algo == GLABC_ALGO_GLMALA)
+            log_acc = ((pk + a.log_q[c]) - prior_c) - kern_c;                             // GLMALA.py:190-193
         else
             log_acc = (pk - prior_c) - kern_c;                                            // GLMCMC.py:96-97, GlobalMCMC.py:60-61
         ind = a.log_u[c] < log_acc ? 1 : 0;                                               // GLMCMC.py:98-99
@@ -361,17 +364,18 @@ __global__ void __launch_bounds__(256) select_kernel(const GenArgs a)
         for (int j = 0; j < YD; ++j) a.y[j * a.stride + c] = y_new[j];                    // GLMCMC.py:87,103
         a.prior_cur[c] = a.prior_prop[r];
         a.kern_cur[c] = a.kern_prop[r];
-        if (a.algo == GLABC_ALGO_GLMCMC) {
+        if (isir) {
             if (is_global)
                 log_w = (a.prior_prop[r] + a.kern_prop[r]) - a.log_q[r];                  // GLMCMC.py:86
-            else
-                flags |= GLABC_FLAG_LOCAL;                                                // GLMCMC.py:100
+            else if (a.algo == GLABC_ALGO_GLMCMC)
+                flags |= GLABC_FLAG_LOCAL;                                                // GLMCMC.py:100; not in GLMALA.py:195-199
         }
         if (a.n_moves) a.n_moves[c] += 1u;
+        a.is_global[c] |= 2;
     }
     if (a.history)
         for (int j = 0; j < D; ++j) a.history[j * a.hist_stride + c] = a.theta[j * a.stride + c];     // GLMCMC.py:89,104
-    if (a.algo == GLABC_ALGO_GLMCMC) {
+    if (isir) {
         a.log_w[c] = log_w;
         a.flags[c] = flags;
     }
@@ -461,7 +465,7 @@ static int pack_common(int algo, const glabc_dist* local, const glabc_dist* glob
                        const glabc_step_io* io, GenArgs* a)
 {
     if (!c || !r || !io) return GLABC_ERR_NULL;
-    if (algo != GLABC_ALGO_GLMCMC && algo != GLABC_ALGO_GLOBALMCMC) return GLABC_ERR_KIND;
+    if (algo != GLABC_ALGO_GLMCMC && algo != GLABC_ALGO_GLOBALMCMC && algo != GLABC_ALGO_GLMALA) return GLABC_ERR_KIND;
     if (io->theta_dim < 1 || io->y_dim < 1 || io->noise_dim < 0) return GLABC_ERR_DIM;
     if (io->n_prop < 1 || (algo == GLABC_ALGO_GLOBALMCMC && io->n_prop != 1)) return GLABC_ERR_ARG;
     if ((int64_t)io->n_prop * c->n_chains > (int64_t)1 << 40) return GLABC_ERR_ARG;
@@ -561,7 +565,7 @@ __attribute__((visibility("default"))) int glabc_select(int algo, const glabc_di
     if (!io->theta_prop || !io->log_q || !io->log_u || !io->u_res || !io->is_global || !io->y_prop || !io->prior_prop ||
         !io->kern_prop || !io->prior_cur || !io->kern_cur)
         return GLABC_ERR_NULL;
-    if (algo == GLABC_ALGO_GLMCMC && (!chains->log_w || !chains->flags)) return GLABC_ERR_NULL;
+    if (algo != GLABC_ALGO_GLOBALMCMC && (!chains->log_w || !chains->flags)) return GLABC_ERR_NULL;
     if (!global && !io->q_cur) return GLABC_ERR_NULL;                     // someone has to supply q(Theta_old)
     if (chains->n_chains == 0) return GLABC_OK;
     hipLaunchKernelGGL(select_kernel, dim3(blocks_for(chains->n_chains)), dim3(256), 0, (hipStream_t)stream, a);

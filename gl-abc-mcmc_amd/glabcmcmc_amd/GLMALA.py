@@ -12,15 +12,28 @@ float32 finite difference (B3).  Not reproducible: the reference reseeds torch /
 ``secrets`` inside every gradient (B2), so two reference runs never agree; here the gradient noise
 is a Philox sub-stream of the run's seed.
 """
-from . import _capi, _host, engine
+from . import _capi, _host, engine, generic
 
 
 def GLMALA(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad,
            filelocation, global_frequency=0, Importance_Proposal=None, batch_size=None, *,
            seed=None, device=None, chain0=0, record_history=True, stats=None, return_device=False,
-           steps_per_launch=None, verbose=True, state_out=None):
+           steps_per_launch=None, verbose=True, state_out=None, path="auto", **generic_kw):
     if Importance_Proposal is None or batch_size is None:
         raise ValueError("GLMALA needs Importance_Proposal and batch_size (GLMALA.py:155,158)")
+    if path not in ("auto", "fused", "generic"):
+        raise ValueError("path must be 'auto', 'fused' or 'generic'")
+    fused_ok = generic.fused_supported(ABCset, (Importance_Proposal,), batch_size) and \
+        engine.model_descriptor(ABCset).sim_kind == _capi.SIM_ABS_GAUSS
+    if path == "generic" or (path == "auto" and not fused_ok):
+        # a Model given as callbacks (generic.py): iSIR through glabc_propose / glabc_select, the MALA move's gradient
+        # through the Model's generate_samples / discrepancy in float64 torch operations
+        return generic.run_glmala(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad, filelocation, global_frequency,
+                                  Importance_Proposal, batch_size, seed=seed, device=device, chain0=chain0,
+                                  record_history=record_history, stats=stats, return_device=return_device, verbose=verbose,
+                                  state_out=state_out, **generic_kw)
+    if generic_kw:
+        raise TypeError("unexpected keyword arguments for the fused path: %s" % sorted(generic_kw))
     model = engine.model_descriptor(ABCset)
     imp = Importance_Proposal.descriptor()
     mala = _capi.Mala(float(tau), float(tau) ** 2, float(ABCset.epsilon) ** 2, int(num_grad), 0)   # GLMALA.py:43,90

@@ -189,6 +189,7 @@ class StepIO(C.Structure):
 
 ALGO_GLMCMC = 0
 ALGO_GLOBALMCMC = 1
+ALGO_GLMALA = 2
 SLOT_REDRAW = 0x40000000
 
 

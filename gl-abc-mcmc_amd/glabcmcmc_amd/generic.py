@@ -246,3 +246,151 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     if state_out is not None:
         state_out.update(chains=chains, prior_cur=prior_cur, kern_cur=kern_cur, callback_device=model.where)
     return _host.finish(hist, chains, single, filelocation, csv_variant, verbose and single, return_device)
+
+
+# ----------------------------------------------------------------------------------------------------------- GLMALA
+def _numerical_gradient(model, theta, num, eps_sq, gen, seeds, d_step=1e-1):
+    """numberical_gradient_logABC (GLMALA.py:46-95) for a batch of rows: central difference (step 0.1) of the synthetic
+    log-likelihood -1/2 log(Sigma + eps^2) - 1/2 mu^2 / (Sigma + eps^2) of `num` simulated discrepancies, the +/- sides on
+    common random numbers, plus the float32 central difference (h = 1e-5) of the prior.  theta is cast to float32 as the
+    reference does (:62); the statistics are float64 (:70-71)."""
+    theta = theta.float()
+    L, d = theta.shape
+    dev = theta.device
+    mu = torch.empty(2, L, d, dtype=torch.float64, device=dev)
+    var = torch.empty(2, L, d, dtype=torch.float64, device=dev)
+    grad_prior = torch.empty(L, d, dtype=torch.float64, device=dev)
+    for k in range(d):
+        e_k = torch.zeros(d, device=dev)
+        e_k[k] = 1.0
+        eps = torch.randn(L * num, model.noise_dim, generator=gen, device=dev) if model.noise_dim else None
+        for side, sign in enumerate((1.0, -1.0)):
+            rows = (theta + sign * d_step * e_k).repeat_interleave(num, dim=0)                  # :78,82
+            if eps is None:                                                                      # :76-77,80-81
+                torch.manual_seed(int(seeds[k]))
+                np.random.seed(int(seeds[k]))
+            dis = model.discrepancy(model.simulate(rows, eps)).view(L, num).double()
+            mu[side, :, k] = dis.mean(dim=1)                                                     # :86-89
+            var[side, :, k] = dis.var(dim=1)
+        grad_prior[:, k] = ((model.prior(theta + e_k * 0.00001) - model.prior(theta - e_k * 0.00001))
+                            / (2 * 0.00001)).double()                                            # :84-85 (float32 difference)
+    logp = -0.5 * torch.log(var + eps_sq) - 0.5 * mu ** 2 / (var + eps_sq)                       # :90-93
+    return (logp[0] - logp[1]) / (2 * d_step) + grad_prior                                       # :94-95
+
+
+def run_glmala(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad, filelocation, global_frequency, Importance_Proposal,
+               batch_size, *, seed=None, device=None, chain0=0, record_history=True, stats=None, return_device=False,
+               verbose=True, state_out=None, callback_device="auto", progress=None):
+    """GLMALA (GLMALA.py:118-230) with the Model as callbacks.  The iSIR global move is glabc_propose -> callbacks ->
+    glabc_select as in GLMCMC; the MALA local move (GLMALA.py:182-200) -- gradient, drift, reverse density -- is evaluated in
+    float64 torch operations on the chains that take it, and its accept / state update / Theta_Re row again by glabc_select.
+    Reference behaviours kept: log_weight_old is not refreshed after MALA moves, the cached gradient is not
+    refreshed after iSIR moves, the prior gradient is a float32 finite difference (B3).  The chain state itself stays
+    float32 (the reference's turns float64 after the first accepted MALA move; Theta_Re is float32 there too)."""
+    lib = _capi.lib()
+    dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
+    n, d, yd = chains.n, chains.d, chains.yd
+    N = int(batch_size)
+    key = engine.draw_seed(seed)
+    model = ModelCallbacks(ABCset, dev, callback_device)
+    if not hasattr(ABCset, "discrepancy"):
+        raise TypeError("GLMALA needs Model.discrepancy (GLMALA.py:78)")
+    global_desc = dist_descriptor(Importance_Proposal, d)
+    global_cb = ProposalCallbacks(Importance_Proposal, dev) if global_desc is None else None
+    tau = float(tau)
+    eps_sq = float(ABCset.epsilon) ** 2                                                          # GLMALA.py:90
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(key & 0x7FFFFFFFFFFFFFFF)
+    host_rng = np.random.Generator(np.random.PCG64(key))
+
+    def discrepancy(y):
+        return model._call(lambda cuda: model._back(ABCset.discrepancy(y if cuda else y.cpu()), y.shape[0])).view(-1)
+    model.discrepancy = discrepancy
+
+    R = N * n
+    f32 = dict(dtype=torch.float32, device=dev)
+    theta_prop = torch.zeros(R, d, **f32)
+    log_q = torch.zeros(R, **f32)
+    nd = model.noise_dim
+    sim_noise = torch.zeros(R, nd, **f32) if nd else None
+    log_u = torch.zeros(n, **f32)
+    u_res = torch.zeros(n, dtype=torch.float64, device=dev)
+    is_global = torch.zeros(n, dtype=torch.int32, device=dev)
+    prior_cur = model.prior(chains.theta.t().contiguous()).clone()
+    kern_cur = model.kernel(chains.y.t().contiguous()).clone()
+    grad = torch.zeros(n, d, dtype=torch.float64, device=dev)                                    # grad_logABC_Theta_old, :146
+    has_grad = torch.zeros(n, dtype=torch.bool, device=dev)
+    hist = _host.allocate_history(num_ite, chains, record_history)
+
+    io = _capi.StepIO()
+    io.n_prop, io.theta_dim, io.y_dim, io.noise_dim = N, d, yd, nd
+    io.theta_prop, io.log_q = theta_prop.data_ptr(), log_q.data_ptr()
+    io.sim_noise = sim_noise.data_ptr() if nd else None
+    io.log_u, io.u_res, io.is_global = log_u.data_ptr(), u_res.data_ptr(), is_global.data_ptr()
+    io.prior_cur, io.kern_cur = prior_cur.data_ptr(), kern_cur.data_ptr()
+    cs = chains.struct()
+    ms = stats.struct() if stats is not None else None
+    run_ = _capi.Run()
+    run_.seed, run_.n_steps, run_.global_frequency, run_.batch_size, run_.hist_stride = key, 1, float(global_frequency), N, n
+    if ms is not None:
+        run_.moments = C.pointer(ms)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    hist_ptr, hist_row_bytes = (hist.data_ptr(), hist[0].numel() * 4) if hist is not None else (0, 0)
+    gp = C.byref(global_desc) if global_desc is not None else None
+    c_norm = -0.5 * d * math.log(2 * math.pi)
+
+    with torch.cuda.device(dev):
+        for i in range(1, num_ite):
+            run_.step0 = i
+            run_.history = hist_ptr + i * hist_row_bytes if hist is not None else None
+            _capi.check(lib.glabc_propose(_capi.ALGO_GLMALA, None, gp, C.byref(cs), C.byref(run_), C.byref(io), stream),
+                        "glabc_propose")
+            if global_cb is not None:                                                           # GLMALA.py:158
+                z, lq = global_cb.forward(R)
+                theta_prop.copy_(z)
+                log_q.copy_(lq)
+            # ---- iSIR candidates of every chain (rows of chains on the local branch are overwritten below) :158-165
+            prior_prop = model.prior(theta_prop)
+            y_prop = model.simulate(theta_prop, sim_noise)
+            kern_prop = model.kernel(y_prop)
+            # ---- MALA move of the chains on the local branch, GLMALA.py:182-200
+            idx = torch.nonzero(is_global == 0).view(-1)
+            L = int(idx.numel())
+            g_new = None
+            if L:
+                th_old = chains.theta.t()[idx]                                                   # (L, d) float32
+                need = ~has_grad[idx]
+                if bool(need.any()):                                                             # :183-184
+                    sub = idx[need]
+                    grad[sub] = _numerical_gradient(model, th_old[need], int(num_grad), eps_sq, gen,
+                                                    host_rng.integers(0, 2 ** 32, d))
+                    has_grad[sub] = True
+                g_old = grad[idx]
+                z = torch.randn(L, d, generator=gen, device=dev)                                 # Local_proposal_forward, :25-44
+                th_new = z * tau + th_old + g_old * tau ** 2 / 2                                 # float64
+                logq_fwd = c_norm - (0.5 * z ** 2).sum(1)
+                g_new = _numerical_gradient(model, th_new, int(num_grad), eps_sq, gen, host_rng.integers(0, 2 ** 32, d))   # :187
+                eps1 = torch.randn(L, nd, generator=gen, device=dev) if nd else None
+                y_new = model.simulate(th_new, eps1)                                             # :188-189
+                e_rev = (th_old.double() - th_new - g_new * tau ** 2 / 2) / tau                  # log_proposal, :97-116
+                rev = c_norm - (0.5 * e_rev ** 2).sum(1)
+                theta_prop[idx] = th_new.float()
+                y_prop[idx] = y_new
+                prior_prop[idx] = model.prior(th_new)
+                kern_prop[idx] = model.kernel(y_new)
+                log_q[idx] = (rev - logq_fwd.double()).float()                                   # the proposal terms of :190-193
+            io.prior_prop, io.y_prop, io.kern_prop = prior_prop.data_ptr(), y_prop.data_ptr(), kern_prop.data_ptr()
+            if global_cb is not None:
+                q_cur = global_cb.log_prob(chains.theta.t().contiguous())
+                io.q_cur = q_cur.data_ptr()
+            _capi.check(lib.glabc_select(_capi.ALGO_GLMALA, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_select")
+            if L:                                                                                # :194-199
+                moved = (is_global[idx] & 2) != 0
+                grad[idx[moved]] = g_new[moved]
+            if progress is not None:
+                progress(i)
+    if stats is not None:
+        stats.steps += num_ite - 1
+    if state_out is not None:
+        state_out.update(chains=chains, grad=grad, has_grad=has_grad, callback_device=model.where)
+    return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)

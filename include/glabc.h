@@ -281,7 +281,15 @@ int glabc_init_weights(const glabc_model* model, const glabc_dist* importance,
  * row-major batch).  A chain on the local branch uses row j = 0 only (theta' = Theta_old + increment, GLMCMC.py:91); its
  * other rows still hold global candidates and are ignored by glabc_select.  All pointers are device pointers.
  * theta_dim and y_dim are free in glabc_select (loops); a descriptor proposal limits theta_dim to GLABC_MAX_DIM. */
-typedef enum glabc_algo { GLABC_ALGO_GLMCMC = 0, GLABC_ALGO_GLOBALMCMC = 1 } glabc_algo;
+typedef enum glabc_algo {
+    GLABC_ALGO_GLMCMC = 0,         /* GLMCMC.py:58-104 */
+    GLABC_ALGO_GLOBALMCMC = 1,     /* GlobalMCMC.py:37-68 */
+    GLABC_ALGO_GLMALA = 2          /* GLMALA.py:150-200: the iSIR move as GLMCMC; on the local branch the caller evaluates the
+                                      MALA proposal (gradient, drift, GLMALA.py:182-193) and puts theta', y', prior', K' in
+                                      row c and the proposal terms log_proposal(theta', grad', Theta_old) - log q_forward in
+                                      log_q[c]; glabc_select takes the accept decision.  `local` stays clear after an accepted
+                                      MALA move (GLMALA.py:195-199) */
+} glabc_algo;
 
 typedef struct glabc_step_io {
     int32_t n_prop;                /* candidate rows per chain: batch_size (GLMCMC.py:66) | 1 (GlobalMCMC) */
@@ -295,7 +303,8 @@ typedef struct glabc_step_io {
                                       DP = theta_dim rounded up to even (the fused kernels' simulator draws) */
     float* log_u;                  /* [n_chains] log(torch.rand(1)), GLMCMC.py:98 */
     double* u_res;                 /* [n_chains] np.random.uniform(0,1), GLMCMC.py:17 */
-    int32_t* is_global;            /* [n_chains] torch.rand(1) < global_frequency, GLMCMC.py:59 */
+    int32_t* is_global;            /* [n_chains] bit 0: torch.rand(1) < global_frequency, GLMCMC.py:59; glabc_select sets
+                                      bit 1 when the chain moved in this iteration */
     /* written by the Model callbacks, read by glabc_select */
     const float* y_prop;           /* [n_prop*n_chains][y_dim]  generate_samples(theta_prop, 1) */
     const float* prior_prop;       /* [n_prop*n_chains]         prior_log_prob(theta_prop) */

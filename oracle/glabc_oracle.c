@@ -1565,7 +1565,7 @@ static void candidate_draws(uint64_t seed, uint64_t chain, uint32_t step, int j,
 static int step_io_check(int algo, const glabc_chains* c, const glabc_run* r, const glabc_step_io* io)
 {
     if (!c || !r || !io) return GLABC_ERR_NULL;
-    if (algo != GLABC_ALGO_GLMCMC && algo != GLABC_ALGO_GLOBALMCMC) return GLABC_ERR_KIND;
+    if (algo != GLABC_ALGO_GLMCMC && algo != GLABC_ALGO_GLOBALMCMC && algo != GLABC_ALGO_GLMALA) return GLABC_ERR_KIND;
     if (io->theta_dim < 1 || io->y_dim < 1 || io->noise_dim < 0) return GLABC_ERR_DIM;
     if (io->n_prop < 1 || (algo == GLABC_ALGO_GLOBALMCMC && io->n_prop != 1)) return GLABC_ERR_ARG;
     if (r->n_steps != 1 || r->tape) return GLABC_ERR_ARG;
@@ -1620,7 +1620,7 @@ ORACLE_API int oracle_propose_redraw(const glabc_dist* local, const glabc_chains
     const int d = io->theta_dim;
     const float sentinel = (float)(7.0 * log(1e-10));
     for (int64_t i = 0; i < c->n_chains; ++i) {
-        if (io->is_global[i] || io->prior_prop[i] != sentinel) continue;
+        if ((io->is_global[i] & 1) || io->prior_prop[i] != sentinel) continue;
         const uint64_t chain = (uint64_t)(c->chain0 + i);
         float e[GLABC_MAX_DIM], z[GLABC_MAX_DIM], lq;
         for (int b = 0; b < 2; ++b) {
@@ -1645,7 +1645,8 @@ ORACLE_API int oracle_select(int algo, const glabc_dist* global, const glabc_cha
     int rc = step_io_check(algo, c, run, io);
     if (rc) return rc;
     if (!global && !io->q_cur) return GLABC_ERR_NULL;
-    if (algo == GLABC_ALGO_GLMCMC && (!c->log_w || !c->flags)) return GLABC_ERR_NULL;
+    if (algo != GLABC_ALGO_GLOBALMCMC && (!c->log_w || !c->flags)) return GLABC_ERR_NULL;
+    const int isir = algo != GLABC_ALGO_GLOBALMCMC;
     const int d = io->theta_dim, yd = io->y_dim, N = io->n_prop;
     const int64_t C = c->n_chains;
     float* lw = (float*)malloc(sizeof(float) * (size_t)(N + 1));
@@ -1653,14 +1654,14 @@ ORACLE_API int oracle_select(int algo, const glabc_dist* global, const glabc_cha
     float* th_old = (float*)malloc(sizeof(float) * (size_t)d);
     if (!lw || !w || !th_old) { free(lw); free(w); free(th_old); return GLABC_ERR_ARG; }
     for (int64_t i = 0; i < C; ++i) {
-        const int is_global = io->is_global[i];
+        const int is_global = io->is_global[i] & 1;
         const float prior_c = io->prior_cur[i], kern_c = io->kern_cur[i];
         for (int k = 0; k < d; ++k) th_old[k] = c->theta[k * c->stride + i];
         float q_state = 0.0f;
         if (io->q_cur) q_state = io->q_cur[i];
         else dist_log_prob(global, th_old, &q_state);
         int ind = 0;
-        if (algo == GLABC_ALGO_GLMCMC && is_global) {
+        if (isir && is_global) {
             if (c->flags[i] & GLABC_FLAG_LOCAL) c->log_w[i] = (prior_c + kern_c) - q_state;       /* GLMCMC.py:60-64 */
             c->flags[i] &= ~GLABC_FLAG_LOCAL;                                                     /* :65 */
             lw[0] = c->log_w[i];
@@ -1685,6 +1686,8 @@ ORACLE_API int oracle_select(int algo, const glabc_dist* global, const glabc_cha
             float log_acc;
             if (algo == GLABC_ALGO_GLOBALMCMC && is_global)
                 log_acc = (((pk + q_state) - io->log_q[i]) - prior_c) - kern_c;                   /* GlobalMCMC.py:44-46 */
+            else if (algo == GLABC_ALGO_GLMALA)
+                log_acc = ((pk + io->log_q[i]) - prior_c) - kern_c;                               /* GLMALA.py:190-193 */
             else
                 log_acc = (pk - prior_c) - kern_c;                                                /* GLMCMC.py:96-97 */
             ind = io->log_u[i] < log_acc ? 1 : 0;
@@ -1695,11 +1698,12 @@ ORACLE_API int oracle_select(int algo, const glabc_dist* global, const glabc_cha
             for (int k = 0; k < yd; ++k) c->y[k * c->stride + i] = io->y_prop[r * yd + k];
             io->prior_cur[i] = io->prior_prop[r];
             io->kern_cur[i] = io->kern_prop[r];
-            if (algo == GLABC_ALGO_GLMCMC) {
+            if (isir) {
                 if (is_global) c->log_w[i] = lw[ind];                                             /* GLMCMC.py:86 */
-                else c->flags[i] |= GLABC_FLAG_LOCAL;                                             /* GLMCMC.py:100 */
+                else if (algo == GLABC_ALGO_GLMCMC) c->flags[i] |= GLABC_FLAG_LOCAL;              /* GLMCMC.py:100, absent from GLMALA.py:195-199 */
             }
             if (c->n_moves) c->n_moves[i] += 1u;
+            io->is_global[i] |= 2;
         }
         /* Theta_Re row and streaming sums, any theta_dim */
         if (run->history)

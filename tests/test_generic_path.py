@@ -398,3 +398,39 @@ def test_dispatch_without_a_device():
     ga = g_.Gamma(torch.tensor([2.0, 3.0]), torch.tensor([1.0, 2.0]))
     assert generic.dist_descriptor(ga, 2) is None and generic.dist_descriptor(dg, 2) is not None
     assert not generic.fused_supported(g_.examples.Mixture.Mixture_set(0.05), (dg, dg), 17)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_kind", ["torch", "protocol"])
+def test_hip_generic_glmala_has_the_law_of_the_fused_kernel(hip, model_kind):
+    """run_glmala with the Model as callbacks (iSIR through propose / select, MALA gradient through the Model's
+    generate_samples / discrepancy) against the fused GLMALA kernel: same pooled second moments, move rate and mean squared
+    jump within the Monte-Carlo error of 16 384 chains (the two use different random streams for the MALA move)."""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import distribution, engine
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    n, T, eps, tau, num_grad, gf, N = 16384, 150, 0.3, 0.3, 20, 0.5, 4
+    ip = distribution.DiagGaussian(2, torch.zeros(2), torch.zeros(2))
+    g = torch.Generator().manual_seed(2)
+    th0 = 1.3 * (torch.randint(0, 2, (n, 2), generator=g).float() * 2 - 1)
+    y0 = th0.abs() + 0.2236 * torch.randn(n, 2, generator=g)
+    dev = torch.device("cuda", 0)
+    res = []
+    for which in ("fused", "generic"):
+        if which == "fused":
+            m = Mixture_set(eps)
+        else:
+            m = TorchMixture(2, eps) if model_kind == "torch" else ProtocolModel(Mixture_set(eps).descriptor())
+        mom = engine.Moments(n, 2, dev)
+        st = {}
+        torch.manual_seed(11)
+        g_.MCMCRunner(m).run_glmala(T + 1, th0, y0, gf, ip, N, tau, num_grad, output_file=None, seed=9, record_history=False,
+                                    stats=mom, verbose=False, state_out=st)
+        sq = (mom.sum_outer[0] + mom.sum_outer[2]).cpu().numpy() / T
+        jump = (mom.sum_jump[0] + mom.sum_jump[2]).cpu().numpy() / T
+        moves = st["chains"].n_moves.cpu().numpy().astype(np.float64) / T
+        res.append((sq, jump, moves))
+    for a, b, name in zip(res[0], res[1], ("theta^2", "squared jump", "move rate")):
+        se = math.sqrt(a.var(ddof=1) / n + b.var(ddof=1) / n)
+        assert abs(a.mean() - b.mean()) < 5 * se, (name, a.mean(), b.mean(), se)
+        assert a.mean() > 0
