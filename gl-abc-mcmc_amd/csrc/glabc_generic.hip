@@ -432,6 +432,15 @@ __global__ void __launch_bounds__(256) simulate_kernel(const SimArgs s)
     }
 }
 
+// test hook: aten_rowsum_rt of each row of x[n_rows][n]
+__global__ void __launch_bounds__(64) rowsum_kernel(const float* __restrict__ x, int n_rows, int n, float* __restrict__ out)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_rows) return;
+    const float* row = x + (int64_t)r * n;
+    out[r] = aten_rowsum_rt([&](int i) { return row[i]; }, n);
+}
+
 }  // namespace glabc
 
 // =================================================================================================
@@ -569,6 +578,15 @@ __attribute__((visibility("default"))) int glabc_select(int algo, const glabc_di
     if (!global && !io->q_cur) return GLABC_ERR_NULL;                     // someone has to supply q(Theta_old)
     if (chains->n_chains == 0) return GLABC_OK;
     hipLaunchKernelGGL(select_kernel, dim3(blocks_for(chains->n_chains)), dim3(256), 0, (hipStream_t)stream, a);
+    return finish();
+}
+
+__attribute__((visibility("default"))) int glabc_selftest_rowsum(const float* x, int32_t n_rows, int32_t n, float* out, void* stream)
+{
+    if (!x || !out) return GLABC_ERR_NULL;
+    if (n_rows < 0 || n < 1) return GLABC_ERR_ARG;
+    if (n_rows == 0) return GLABC_OK;
+    hipLaunchKernelGGL(rowsum_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, n_rows, n, out);
     return finish();
 }
 

@@ -25,12 +25,18 @@ from . import _capi, _host, engine
 from .flows import RealNVP
 
 
-def resample(W, N):
-    """Systematic resampling (GLMCMC_NFs.py:29-40): counts of u_i = (u + i)/N below each cumulative weight."""
-    u = (torch.rand(1, device=W.device) + torch.arange(N, device=W.device)) / N
-    Psum = torch.cumsum(W, dim=0)
-    idx = torch.searchsorted(Psum, u, right=True)               # u_i < Psum[j]  <=>  index j gets u_i
-    return idx.clamp_(max=W.numel() - 1)
+def resample(W, N, u0=None):
+    """Systematic resampling (GLMCMC_NFs.py:29-40): draw i of u_i = (u0 + i)/N goes to the first index j whose cumulative
+    weight exceeds it; draws at or beyond the last cumulative weight find no index and are dropped, as the reference's
+    counting loop drops them (the result then has fewer than N entries).  The reference's float32 ``torch.cumsum`` on the CPU
+    accumulates in double and rounds every partial sum to float32 -- spelled out here so that the device scan (whose order of
+    additions differs) gives the same float32 values."""
+    if u0 is None:
+        u0 = torch.rand(1, device=W.device)
+    u = (torch.as_tensor(u0, dtype=torch.float32, device=W.device).view(1) + torch.arange(N, device=W.device)) / N
+    Psum = torch.cumsum(W.double(), dim=0).to(W.dtype)
+    idx = torch.searchsorted(Psum, u, right=True)               # Psum[j-1] <= u_i < Psum[j]  <=>  index j gets u_i
+    return idx[idx < W.numel()]
 
 
 def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,

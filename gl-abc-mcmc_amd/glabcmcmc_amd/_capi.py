@@ -245,6 +245,7 @@ ENTRY_POINTS = {
     "glabc_moments_esjd": (C.c_int, [_P(Moments), C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_selftest_numerics": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "glabc_selftest_sqrt": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "glabc_selftest_rowsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "glabc_version": (C.c_int, []),
     "glabc_status_string": (C.c_char_p, [C.c_int]),
     "glabc_last_hip_error": (C.c_int, []),

@@ -436,6 +436,8 @@ int glabc_kde_train_weights(const glabc_model* model, const float* theta, const 
  * exactly rounded square root (*mismatches is a device counter the caller zeroed). */
 int glabc_selftest_numerics(int op, const uint32_t* in, uint32_t* out, int64_t n, void* stream);
 int glabc_selftest_sqrt(uint32_t first_bits, uint32_t last_bits, uint64_t* mismatches, void* stream);
+/* torch.sum's float32 association for rows of any length as glabc_select evaluates it: x[n_rows][n] -> out[n_rows] */
+int glabc_selftest_rowsum(const float* x, int32_t n_rows, int32_t n, float* out, void* stream);
 
 int glabc_version(void);
 const char* glabc_status_string(int status);

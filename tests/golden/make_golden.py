@@ -455,8 +455,87 @@ def primitives():
             np.random.uniform = saved
         ws.append((w, ran, -1 if ind is None else ind))
     out["weight_sampling_cases"] = np.array(repr(ws))
+    # ---- everything below was added after round 1: appended so that the arrays above keep their random stream ----
+    # Gamma.log_prob (distribution.py:123-137): float64 through scipy.stats.gamma.pdf; negative coordinates, an exact zero,
+    # the bulk, and tails far enough out for the pdf to underflow (-inf although a logpdf would be finite)
+    for tag, shape, rate in (("a", [2.0, 3.0], [1.0, 2.0]), ("b", [0.5], [3.0]), ("c", [1.0, 7.5, 2.25], [0.5, 1.5, 4.0])):
+        g = rdist.Gamma(torch.tensor(shape), torch.tensor(rate))
+        k = len(shape)
+        z = rng.gamma(np.array(shape), 1.0 / np.array(rate), (300, k))
+        z[:6] = -np.abs(rng.standard_normal((6, k))) * (np.array(shape) / np.array(rate))
+        z[6, 0] = 0.0
+        z[7:40] *= np.exp(rng.uniform(0.0, 6.5, (33, 1)))
+        z[40:48] *= np.exp(rng.uniform(-12.0, -3.0, (8, 1)))
+        out["gm_%s_shape" % tag] = np.array(shape, np.float32)
+        out["gm_%s_rate" % tag] = np.array(rate, np.float32)
+        out["gm_%s_z" % tag] = z
+        out["gm_%s_log_prob" % tag] = g.log_prob(torch.from_numpy(z)).numpy()
+    # torch.sum rows long enough for the 4-accumulator and cascade levels of ATen's sum (iSIR batches beyond 16)
+    for n in (18, 31, 32, 33, 63, 64, 65, 100, 128, 255, 256, 257, 511, 512, 513, 1000, 2049, 4099):
+        x = (rng.standard_normal((8, n)) * rng.choice([1e-3, 1.0, 1e3], (8, n))).astype(np.float32)
+        out["rowsum_%d_x" % n] = x
+        out["rowsum_%d_sum" % n] = np.array([torch.sum(torch.from_numpy(r)).item() for r in x], np.float32)
+    # resample (GLMCMC_NFs.py:29-40): systematic resampling; the module imports the third-party normflows at its top
+    # (absent here) but resample itself is plain torch -- an empty placeholder module satisfies the import
+    sys.modules.setdefault("normflows", types.ModuleType("normflows"))
+    import glabcmcmc.GLMCMC_NFs as rnf
+    cases = []
+    for i, (P, N, kind) in enumerate(((10, 10, "flat"), (1000, 1000, "exp"), (1000, 1000, "short"), (257, 300, "spiky"),
+                                      (64, 7, "exp"), (5, 40, "short"), (1000, 1000, "zeros"))):
+        w = {"flat": np.ones(P), "exp": np.exp(rng.standard_normal(P) * 2), "short": np.exp(rng.standard_normal(P)),
+             "spiky": np.where(rng.random(P) < 0.02, 1.0, 1e-9), "zeros": np.where(rng.random(P) < 0.5, 0.0, rng.random(P))}[kind]
+        w = (w / w.sum()).astype(np.float32)
+        if kind == "short":
+            w = (w * np.float32(0.83)).astype(np.float32)          # cumulative sum ends below 1: the last draws find no index
+        u0 = np.float32(rng.integers(0, 1 << 24)) * np.float32(2.0 ** -24)
+        saved = torch.rand
+        torch.rand = lambda *a, u0=u0, **k: torch.tensor([u0])
+        try:
+            idx = rnf.resample(torch.from_numpy(w), N)
+        finally:
+            torch.rand = saved
+        out["resample_%d_w" % i], out["resample_%d_u0" % i] = w, u0
+        out["resample_%d_idx" % i] = idx.numpy().astype(np.int64)
+        cases.append((i, P, N, kind, int(idx.numel())))
+    out["resample_cases"] = np.array(repr(cases))
     np.savez_compressed(os.path.join(HERE, "primitives.npz"), **out)
     print("primitives: %d arrays" % len(out))
+
+
+def csv_fixture():
+    """The CSV side effect as the reference writes it (GlobalMCMC.py:70-76 -- the variant that re-writes the previous
+    block at the tail, SURVEY B9 -- and GLMCMC.py:105-111) for num_ite = 12 005: the chain and the SHA-256 of the file."""
+    import hashlib
+    import tempfile
+    L = oracle_lib.load()
+    out = {}
+    T = 12004
+    for algo, cfg in (("globalmcmc", dict(epsilon=0.3, gf=0.5, N=1, T=T, seed=61, local=G2(0.35), **{"global": G2(1.0)})),
+                      ("glmcmc", dict(epsilon=0.3, gf=0.7, N=3, T=T, seed=62, local=G2(0.35), **{"global": G2(1.0)}))):
+        P = cfg["N"]
+        u, r, z = philox_tape(L, cfg["seed"], 0, T, P, 2, 2, False, False, cfg["gf"])
+        tape = Tape(u, r, z, 2, np.float32(cfg["gf"]), algo == "glmcmc")
+        theta0 = np.array([1.4, -1.3], np.float32)
+        y0 = np.array([1.5, 1.45], np.float32)
+        path = os.path.join(tempfile.mkdtemp(), "chain.csv")
+        model, local, glob = make_model(cfg), make_dist(cfg["local"]), make_dist(cfg["global"])
+        with patched(tape):
+            if algo == "glmcmc":
+                chain = rglmcmc.GLMCMC(model, T + 1, torch.from_numpy(theta0), torch.from_numpy(y0).view(1, -1), local, path,
+                                       cfg["gf"], glob, cfg["N"])
+            else:
+                chain = rglobal.GlobalMCMC(model, T + 1, torch.from_numpy(theta0), torch.from_numpy(y0).view(1, -1), glob, path,
+                                           cfg["gf"], local)
+        data = open(path, "rb").read()
+        lines = data.decode().splitlines()
+        out[algo + "_chain"] = chain.numpy().copy()
+        out[algo + "_sha256"] = np.array(hashlib.sha256(data).hexdigest())
+        out[algo + "_n_lines"] = np.array(len(lines))
+        out[algo + "_head"] = np.array("\n".join(lines[:3]))
+        out[algo + "_tail"] = np.array("\n".join(lines[-3:]))
+        out[algo + "_cfg"] = np.array(repr(cfg))
+        print("csv %s: %d lines for %d iterations, %d bytes" % (algo, len(lines), T + 1, len(data)))
+    np.savez_compressed(os.path.join(HERE, "csv.npz"), **out)
 
 
 def gradient_fixture():
@@ -640,6 +719,8 @@ if __name__ == "__main__":
         aglmcmc_fixture()
     if not want or "primitives" in want:
         primitives()
+    if not want or "csv" in want:
+        csv_fixture()
     if not want or "glmala_gradient" in want:
         gradient_fixture()
     for name, (algo, cfg, mode) in SAMPLER_FIXTURES.items():

@@ -434,3 +434,16 @@ def test_hip_generic_glmala_has_the_law_of_the_fused_kernel(hip, model_kind):
         se = math.sqrt(a.var(ddof=1) / n + b.var(ddof=1) / n)
         assert abs(a.mean() - b.mean()) < 5 * se, (name, a.mean(), b.mean(), se)
         assert a.mean() > 0
+
+
+@pytest.mark.gpu
+def test_hip_rowsum_of_any_length_matches_torch_sum(hip):
+    """aten_rowsum_rt on the device against torch.sum's values (tests/golden/primitives.npz rowsum_*), n = 1 ... 4099:
+    the four scalar lanes, the 8-wide vectors over four accumulators, ATen's cascade levels from 512 elements on"""
+    from test_oracle_golden import ROWSUM_LENGTHS
+    p = load_golden("primitives")
+    for n in ROWSUM_LENGTHS:
+        x = torch.from_numpy(np.ascontiguousarray(p["rowsum_%d_x" % n])).cuda()
+        out = torch.empty(x.shape[0], dtype=torch.float32, device="cuda")
+        assert hip.glabc_selftest_rowsum(x.data_ptr(), x.shape[0], n, out.data_ptr(), None) == 0
+        assert np.array_equal(bits(out.cpu().numpy()), bits(p["rowsum_%d_sum" % n])), n

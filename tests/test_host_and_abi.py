@@ -155,6 +155,52 @@ def test_csv_side_effect_matches_reference_schedule(tmp_path):
     assert len(reference_rows(12005, "global")) > 12005          # the reference really duplicates rows
 
 
+def test_csv_equals_the_file_the_reference_wrote(tmp_path):
+    """tests/golden/csv.npz: chains of 12 005 iterations and the SHA-256 of the CSV files the REFERENCE's GlobalMCMC
+    (GlobalMCMC.py:70-76, duplicated tail block) and GLMCMC (GLMCMC.py:105-111) wrote for them; _host.write_csv must
+    produce the same bytes."""
+    import hashlib
+    from helpers import load_golden
+    from glabcmcmc_amd import _host
+    g = load_golden("csv")
+    for algo, variant in (("globalmcmc", "global"), ("glmcmc", "glmcmc")):
+        f = tmp_path / (algo + ".csv")
+        _host.write_csv(torch.from_numpy(g[algo + "_chain"]), str(f), variant)
+        data = open(f, "rb").read()
+        lines = data.decode().splitlines()
+        assert len(lines) == int(g[algo + "_n_lines"]), algo
+        assert "\n".join(lines[:3]) == str(g[algo + "_head"]) and "\n".join(lines[-3:]) == str(g[algo + "_tail"])
+        assert hashlib.sha256(data).hexdigest() == str(g[algo + "_sha256"]), algo
+    assert int(g["globalmcmc_n_lines"]) == 22005 and int(g["glmcmc_n_lines"]) == 12005      # B9: 10 000 rows written twice
+
+
+def resample_cases():
+    from helpers import load_golden
+    p = load_golden("primitives")
+    for i, P, N, kind, n_out in eval(str(p["resample_cases"])):
+        yield i, P, N, kind, n_out, p["resample_%d_w" % i], p["resample_%d_u0" % i], p["resample_%d_idx" % i]
+
+
+def test_resample_matches_the_reference_function():
+    """GLMCMC_NFs.resample against the reference's resample (GLMCMC_NFs.py:29-40) on the golden cases, including
+    cumulative sums that end below 1 (the reference then returns fewer than N indices) and zero weights"""
+    from glabcmcmc_amd.GLMCMC_NFs import resample
+    seen_short = 0
+    for i, P, N, kind, n_out, w, u0, want in resample_cases():
+        got = resample(torch.from_numpy(w), N, u0=float(u0)).numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (i, kind)
+        seen_short += int(len(want) < N)
+    assert seen_short >= 2
+
+
+@pytest.mark.gpu
+def test_resample_on_the_gpu_matches_the_reference_function():
+    from glabcmcmc_amd.GLMCMC_NFs import resample
+    for i, P, N, kind, n_out, w, u0, want in resample_cases():
+        got = resample(torch.from_numpy(w).cuda(), N, u0=float(u0)).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (i, kind)
+
+
 def test_runner_creates_output_dir(tmp_path):
     import glabcmcmc_amd as g
     d = tmp_path / "a" / "b"

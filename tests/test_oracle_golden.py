@@ -105,8 +105,11 @@ def test_mixture_callbacks(oracle, prim, eps):
     _close(o, prim[tag + "_logk"])
 
 
+ROWSUM_LENGTHS = list(range(1, 18)) + [18, 31, 32, 33, 63, 64, 65, 100, 128, 255, 256, 257, 511, 512, 513, 1000, 2049, 4099]
+
+
 def test_rowsum_order(oracle, prim):
-    for n in range(1, 18):
+    for n in ROWSUM_LENGTHS:
         x = prim["rowsum_%d_x" % n]
         got = np.array([oracle.oracle_aten_rowsum_f32(r.ctypes.data, n) for r in np.ascontiguousarray(x)], np.float32)
         assert np.array_equal(bits(got), bits(prim["rowsum_%d_sum" % n])), n
