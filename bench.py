@@ -410,6 +410,13 @@ def main():
                         # (v_pk_* 5.4, v_mad_u64_u32 4.2, v_fma_f32 3.2 cycles) saturates at 6.4e11 wave-insts/s on the
                         # chip (524 288 chains = 8 waves/SIMD); one wave per SIMD -- the 65 536-chain shape -- cannot
                         # issue faster than one instruction per ~4.7 cycles.
+                        # against the guide (MI355X_MICROARCH.md constants table: v_fma_f32 wave64 = 2 cycles on a SIMD-32,
+                        # 4 for one wave alone): 1024 SIMDs x 2.4 GHz / 2 cycles.  The 65 536-chain shape is ONE wave
+                        # per SIMD, whose own ceiling is half of that.
+                        "vector_peak_wave_insts_per_s": 1024 * 2.4e9 / 2,
+                        "frac_of_vector_peak": wave_insts_per_s / (1024 * 2.4e9 / 2),
+                        "one_wave_per_simd_peak_wave_insts_per_s": 1024 * 2.4e9 / 4,
+                        "frac_of_one_wave_peak": wave_insts_per_s / (1024 * 2.4e9 / 4) if n <= 65536 else None,
                         "issue_peak_wave_insts_per_s": 1024 * 1.0e9,
                         "issue_frac": wave_insts_per_s / (1024 * 1.0e9),
                         "mix_saturated_wave_insts_per_s": 6.4e11,
