@@ -26,6 +26,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/glabc.h"
@@ -41,11 +42,19 @@ constexpr int NF_V4_OFF = NF_B1_OFF + NF_H;
 constexpr int NF_B3_OFF = NF_V4_OFF + 4 * NF_H;
 constexpr int NF_BLOCK_FLOATS = NF_B3_OFF + 4;                // = GLABC_NF_COUPLING_FLOATS
 static_assert(NF_BLOCK_FLOATS == GLABC_NF_COUPLING_FLOATS, "parameter block layout");
+// The LDS image of a block puts the 3 KiB of vectors FIRST and W2^T behind them: every vector element is then within the
+// 16-bit immediate offset of a ds_read from one base register.  (With the global layout the vectors sit at byte 66 560, past
+// that range, and the compiler kept one address VGPR per accumulator-init / epilogue read -- the spills of round 1.)
+constexpr int L_W1 = 0, L_B1 = NF_H, L_V4 = 2 * NF_H, L_B3 = L_V4 + 4 * NF_H, L_W2 = L_B3 + 4;
+static_assert((L_W2 * 4) % 16 == 0 && L_W2 + NF_H * NF_H == NF_BLOCK_FLOATS, "LDS image layout");
 
 #ifndef GLABC_NF_WAVES
-#define GLABC_NF_WAVES 8
+#define GLABC_NF_WAVES 12
 #endif
-constexpr int NF_WAVES = GLABC_NF_WAVES;                      // waves per workgroup (one workgroup per CU): 8 = two per SIMD
+// waves per workgroup (one workgroup per CU).  12 = three per SIMD: with the rows' state in LDS and the vectors addressed
+// from one base register the pair kernel needs 168 VGPRs (no scratch), so three waves fit a SIMD's 512 and one wave's
+// LDS / VALU / epilogue gaps are filled by two others' MFMAs: 8 waves 104, 12 waves 112 TFLOP/s (profiles/r02_nf_*)
+constexpr int NF_WAVES = GLABC_NF_WAVES;
 constexpr int NF_MAX_PAIRS = 5;                               // 64-row pairs a wave keeps in registers, at most
 constexpr int NF_CUS = 256;
 
@@ -62,6 +71,7 @@ struct NfArgs {
     int64_t n_rows, row0;
     uint32_t seed_lo, seed_hi;
     int32_t rows_per_wg;          // multiple of 64 (pairs), of 32 in tile mode
+    int32_t state_floats_per_wave; // pair mode: 192 floats (2 tiles x 3 x 32) per pair slot of a wave
 };
 
 // (shift, log_s) of one coupling for this lane's two rows (one in tile a, one in tile b), conditioner inputs z0a / z0b;
@@ -78,14 +88,14 @@ __device__ __forceinline__ void coupling_params2(const float* __restrict__ lds, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        a0[r] = b0[r] = lds[NF_V4_OFF + 4 * i];
-        a1[r] = b1[r] = lds[NF_V4_OFF + 4 * (i + 32)];
-        a2[r] = b2[r] = lds[NF_V4_OFF + 4 * (i + 64)];
-        a3[r] = b3[r] = lds[NF_V4_OFF + 4 * (i + 96)];
+        a0[r] = b0[r] = lds[L_V4 + 4 * i];
+        a1[r] = b1[r] = lds[L_V4 + 4 * (i + 32)];
+        a2[r] = b2[r] = lds[L_V4 + 4 * (i + 64)];
+        a3[r] = b3[r] = lds[L_V4 + 4 * (i + 96)];
     }
-    const float* w1 = lds + NF_W1_OFF + half;
-    const float* bb1 = lds + NF_B1_OFF + half;
-    const float* wt = lds + NF_W2_OFF + half * NF_H + col;
+    const float* w1 = lds + L_W1 + half;
+    const float* bb1 = lds + L_B1 + half;
+    const float* wt = lds + L_W2 + half * NF_H + col;
 #pragma unroll 4
     for (int s = 0; s < 64; ++s) {
         const float w = w1[2 * s], bia = bb1[2 * s];
@@ -107,7 +117,7 @@ __device__ __forceinline__ void coupling_params2(const float* __restrict__ lds, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float2 v = *reinterpret_cast<const float2*>(lds + NF_V4_OFF + 4 * i + 1);
+            const float2 v = *reinterpret_cast<const float2*>(lds + L_V4 + 4 * i + 1);
             const float ha = __builtin_fmaxf(xa[r], 0.0f), hb = __builtin_fmaxf(xb[r], 0.0f);
             pa0 = __builtin_fmaf(v.x, ha, pa0);
             pa1 = __builtin_fmaf(v.y, ha, pa1);
@@ -122,7 +132,7 @@ __device__ __forceinline__ void coupling_params2(const float* __restrict__ lds, 
     epilogue(a3, b3, 3);
     const float qa0 = __shfl_xor(pa0, 32, 64), qa1 = __shfl_xor(pa1, 32, 64);
     const float qb0 = __shfl_xor(pb0, 32, 64), qb1 = __shfl_xor(pb1, 32, 64);
-    const float b30 = lds[NF_B3_OFF + 0], b31 = lds[NF_B3_OFF + 1];
+    const float b30 = lds[L_B3 + 0], b31 = lds[L_B3 + 1];
     shift_a = ((half ? qa0 : pa0) + (half ? pa0 : qa0)) + b30;
     log_s_a = ((half ? qa1 : pa1) + (half ? pa1 : qa1)) + b31;
     shift_b = ((half ? qb0 : pb0) + (half ? pb0 : qb0)) + b30;
@@ -138,14 +148,14 @@ __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        acc0[r] = lds[NF_V4_OFF + 4 * i];
-        acc1[r] = lds[NF_V4_OFF + 4 * (i + 32)];
-        acc2[r] = lds[NF_V4_OFF + 4 * (i + 64)];
-        acc3[r] = lds[NF_V4_OFF + 4 * (i + 96)];
+        acc0[r] = lds[L_V4 + 4 * i];
+        acc1[r] = lds[L_V4 + 4 * (i + 32)];
+        acc2[r] = lds[L_V4 + 4 * (i + 64)];
+        acc3[r] = lds[L_V4 + 4 * (i + 96)];
     }
-    const float* w1 = lds + NF_W1_OFF + half;
-    const float* b1 = lds + NF_B1_OFF + half;
-    const float* wt = lds + NF_W2_OFF + half * NF_H + col;                // W2^T[2s + half][32t + col]
+    const float* w1 = lds + L_W1 + half;
+    const float* b1 = lds + L_B1 + half;
+    const float* wt = lds + L_W2 + half * NF_H + col;                // W2^T[2s + half][32t + col]
 #pragma unroll 8
     for (int s = 0; s < 64; ++s) {
         const float h1 = __builtin_fmaxf(__builtin_fmaf(w1[2 * s], z0, b1[2 * s]), 0.0f);
@@ -160,7 +170,7 @@ __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, f
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float2 v = *reinterpret_cast<const float2*>(lds + NF_V4_OFF + 4 * i + 1);     // (W3[0][i], W3[1][i])
+            const float2 v = *reinterpret_cast<const float2*>(lds + L_V4 + 4 * i + 1);     // (W3[0][i], W3[1][i])
             const float h2 = __builtin_fmaxf(acc[r], 0.0f);
             p0 = __builtin_fmaf(v.x, h2, p0);
             p1 = __builtin_fmaf(v.y, h2, p1);
@@ -175,54 +185,95 @@ __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, f
     const float q0 = __shfl_xor(p0, 32, 64), q1 = __shfl_xor(p1, 32, 64);
     const float lo0 = half ? q0 : p0, hi0 = half ? p0 : q0;
     const float lo1 = half ? q1 : p1, hi1 = half ? p1 : q1;
-    shift = (lo0 + hi0) + lds[NF_B3_OFF + 0];
-    log_s = (lo1 + hi1) + lds[NF_B3_OFF + 1];
+    shift = (lo0 + hi0) + lds[L_B3 + 0];
+    log_s = (lo1 + hi1) + lds[L_B3 + 1];
 }
 
-template <bool INVERSE, int NP>
+// Initial state of one row: forward = the base distribution's draw (nf.distributions.base.DiagGaussian.forward: z = loc +
+// exp(log_scale)*eps, log_p = C - sum(log_scale + 0.5 eps^2)), inverse = the point itself with log_q = 0.
+template <bool INVERSE>
+__device__ __forceinline__ void nf_row_init(const NfArgs& a, int64_t row, float& z0, float& z1, float& lq)
+{
+    const int64_t rr = row < a.n_rows ? row : a.n_rows - 1;
+    if (INVERSE) {
+        z0 = a.in[rr];
+        z1 = a.in[a.n_rows + rr];
+        lq = 0.0f;
+        return;
+    }
+    float e0, e1;
+    if (a.in) {
+        e0 = a.in[rr];
+        e1 = a.in[a.n_rows + rr];
+    } else {
+        const uint64_t gid = (uint64_t)(a.row0 + rr);
+        glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, 0u, a.seed_lo, a.seed_hi);
+        glabc_normal_pair(w.v[0], w.v[1], &e0, &e1);
+    }
+    z0 = a.base_loc[0] + a.base_scale[0] * e0;
+    z1 = a.base_loc[1] + a.base_scale[1] * e1;
+    lq = a.base_c0 - ((a.base_log_scale[0] + 0.5f * (e0 * e0)) + (a.base_log_scale[1] + 0.5f * (e1 * e1)));
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void nf_row_apply(float shift, float log_s, float& z0, float& z1, float& lq)
+{
+    if (INVERSE) {                             // flows reversed: Permute^-1 (the swap again) first, conditioner input z1
+        const float t0 = z1, t1 = z0;
+        z0 = t0;
+        z1 = (t1 - shift) * glabc_expf_b(-log_s);
+        lq = lq + (-log_s);
+    } else {
+        const float nz = z1 * glabc_expf_b(log_s) + shift;
+        lq = lq - log_s;                       // log_q -= log_det
+        z1 = z0;                               // Permute(2, 'swap')
+        z0 = nz;
+    }
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void nf_row_store(const NfArgs& a, int64_t row, float z0, float z1, float lq)
+{
+    if (INVERSE) {
+        // + q0.log_prob(z): C - sum(log_scale + 0.5 ((z - loc)/exp(log_scale))^2)
+        const float e0 = (z0 - a.base_loc[0]) / a.base_scale[0], e1 = (z1 - a.base_loc[1]) / a.base_scale[1];
+        const float lp = a.base_c0 - ((a.base_log_scale[0] + 0.5f * (e0 * e0)) + (a.base_log_scale[1] + 0.5f * (e1 * e1)));
+        a.log_q[row] = lq + lp;
+    } else {
+        a.z_out[row] = z0;
+        a.z_out[a.n_rows + row] = z1;
+        a.log_q[row] = lq;
+    }
+}
+
+// PAIR mode (TILE_MODE false): the workgroup's 64-row pairs are dealt round-robin to its waves (pair p -> wave p % NF_WAVES)
+// and a wave walks its pairs coupling by coupling.  The rows' running state (z0, z1, log_q: 3 floats per row) lives in LDS
+// behind the parameter image -- the 128 accumulator registers + operands of coupling_params2 leave no room for it in the 256
+// VGPRs of a wave at two waves per SIMD (it used to be spilled to scratch), and six ds_read / ds_write per 512 MFMAs are free.
+// TILE mode: one 32-row tile per wave, state in registers (the form for inputs of at most one tile per CU).
+template <bool INVERSE, bool TILE_MODE>
 __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31;
-    constexpr bool TILE_MODE = (NP == 0);                              // one 32-row tile per wave (small inputs)
-    constexpr int NT = TILE_MODE ? 1 : 2 * NP, NPAIR = TILE_MODE ? 1 : NP;
-    const int n_pairs = a.rows_per_wg / 64;                            // 64-row pairs of 32-row tiles in this workgroup
     const int64_t wg_row0 = (int64_t)blockIdx.x * a.rows_per_wg;
-    auto tile_row = [&](int q) -> int64_t {
-        if (TILE_MODE) return wg_row0 + (int64_t)wave * 32 + col;
-        return wg_row0 + (int64_t)(wave + (q >> 1) * NF_WAVES) * 64 + (q & 1) * 32 + col;
-    };
+    const int n_pairs = a.rows_per_wg / 64;                            // pair mode: 64-row pairs in this workgroup
+    float* st = lds + NF_BLOCK_FLOATS + wave * a.state_floats_per_wave;   // [slot][tile a/b][z0, z1, lq][32 rows]
 
-    // Pair p of the workgroup (rows wg_row0 + 64p .. +63) belongs to wave p % NF_WAVES, slot p / NF_WAVES: when the
-    // pairs do not divide evenly the extra ones land on waves 0.., i.e. on different SIMDs.  Tile 2q is the first
-    // 32 rows of the wave's q-th pair, tile 2q+1 the second.
-    float z0[NT], z1[NT], lq[NT];
-    bool valid[NT], active[NPAIR];
-#pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        active[q >> 1] = TILE_MODE ? (wave * 32 < a.rows_per_wg) : (wave + (q >> 1) * NF_WAVES < n_pairs);   // wave-uniform
-        const int64_t row = tile_row(q);
-        valid[q] = active[q >> 1] && row < a.n_rows;
-        const int64_t rr = valid[q] ? row : a.n_rows - 1;
-        if (INVERSE) {
-            z0[q] = a.in[rr];
-            z1[q] = a.in[a.n_rows + rr];
-            lq[q] = 0.0f;
-        } else {
-            float e0, e1;
-            if (a.in) {
-                e0 = a.in[rr];
-                e1 = a.in[a.n_rows + rr];
-            } else {
-                const uint64_t gid = (uint64_t)(a.row0 + rr);
-                glabc_u32x4 w = glabc_philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), 0u, 0u, a.seed_lo, a.seed_hi);
-                glabc_normal_pair(w.v[0], w.v[1], &e0, &e1);
-            }
-            // base DiagGaussian(2).forward: z = loc + exp(log_scale)*eps ; log_p = C - sum(log_scale + 0.5 eps^2)
-            z0[q] = a.base_loc[0] + a.base_scale[0] * e0;
-            z1[q] = a.base_loc[1] + a.base_scale[1] * e1;
-            lq[q] = a.base_c0 - ((a.base_log_scale[0] + 0.5f * (e0 * e0)) + (a.base_log_scale[1] + 0.5f * (e1 * e1)));
+    float z0 = 0.0f, z1 = 0.0f, lq = 0.0f;                             // tile mode only
+    const bool tile_active = wave * 32 < a.rows_per_wg;                // wave-uniform
+    if constexpr (TILE_MODE) {
+        if (tile_active) nf_row_init<INVERSE>(a, wg_row0 + (int64_t)wave * 32 + col, z0, z1, lq);
+    } else {
+        for (int p = wave, slot = 0; p < n_pairs; p += NF_WAVES, ++slot) {
+            // lane l initialises row 64p + l of the pair: tile a = lanes 0..31, tile b = lanes 32..63
+            float i0, i1, il;
+            nf_row_init<INVERSE>(a, wg_row0 + (int64_t)p * 64 + lane, i0, i1, il);
+            float* s = st + slot * 192 + (lane >> 5) * 96 + col;
+            s[0] = i0;
+            s[32] = i1;
+            s[64] = il;
         }
     }
 
@@ -232,57 +283,51 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
         {
             const float4* src = reinterpret_cast<const float4*>(a.params + (int64_t)c * NF_BLOCK_FLOATS);
             float4* dst = reinterpret_cast<float4*>(lds);
-            for (int i = threadIdx.x; i < NF_BLOCK_FLOATS / 4; i += 64 * NF_WAVES) dst[i] = src[i];
+            constexpr int W2_VEC = NF_H * NF_H / 4, SMALL_VEC = (NF_BLOCK_FLOATS - NF_H * NF_H) / 4;
+            for (int i = threadIdx.x; i < W2_VEC; i += 64 * NF_WAVES) dst[L_W2 / 4 + i] = src[i];              // W2^T
+            for (int i = threadIdx.x; i < SMALL_VEC; i += 64 * NF_WAVES) dst[i] = src[W2_VEC + i];             // W1 | b1 | V4 | b3
         }
         __syncthreads();
-        auto apply = [&](int q, float shift, float log_s, float t0, float t1) {
-            if (INVERSE) {
-                z0[q] = t0;
-                z1[q] = (t1 - shift) * glabc_expf_b(-log_s);
-                lq[q] = lq[q] + (-log_s);
-            } else {
-                const float nz = z1[q] * glabc_expf_b(log_s) + shift;
-                lq[q] = lq[q] - log_s;                                 // log_q -= log_det
-                z1[q] = z0[q];                                         // Permute(2, 'swap')
-                z0[q] = nz;
-            }
-        };
-        // inverse: flows reversed -> Permute^-1 (the swap again) first, so the conditioner input is z1
         if constexpr (TILE_MODE) {
-            if (active[0]) {
-                const float ca = INVERSE ? z1[0] : z0[0], ta = z0[0];
-                float sa, la;
-                coupling_params(lds, ca, lane, sa, la);
-                apply(0, sa, la, ca, ta);
+            if (tile_active) {
+                float sh, ls;
+                coupling_params(lds, INVERSE ? z1 : z0, lane, sh, ls);
+                nf_row_apply<INVERSE>(sh, ls, z0, z1, lq);
             }
         } else {
-#pragma unroll
-            for (int q = 0; q < NT; q += 2) {
-                if (!active[q >> 1]) continue;
-                const float ca = INVERSE ? z1[q] : z0[q], cb = INVERSE ? z1[q + 1] : z0[q + 1];
-                const float ta = z0[q], tb = z0[q + 1];
+            for (int p = wave, slot = 0; p < n_pairs; p += NF_WAVES, ++slot) {
+                float* s = st + slot * 192 + col;                      // both lanes of a row read the same words
+                float a0 = s[0], a1 = s[32], al = s[64], b0 = s[96], b1 = s[128], bl = s[160];
                 float sa, la, sb, lb;
-                coupling_params2(lds, ca, cb, lane, sa, la, sb, lb);
-                apply(q, sa, la, ca, ta);
-                apply(q + 1, sb, lb, cb, tb);
+                coupling_params2(lds, INVERSE ? a1 : a0, INVERSE ? b1 : b0, lane, sa, la, sb, lb);
+                nf_row_apply<INVERSE>(sa, la, a0, a1, al);
+                nf_row_apply<INVERSE>(sb, lb, b0, b1, bl);
+                if (lane < 32) {
+                    s[0] = a0;
+                    s[32] = a1;
+                    s[64] = al;
+                    s[96] = b0;
+                    s[128] = b1;
+                    s[160] = bl;
+                }
             }
         }
     }
 
-#pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        const int64_t row = tile_row(q);
-        if (valid[q] && lane < 32) {
-            if (INVERSE) {
-                // + q0.log_prob(z): C - sum(log_scale + 0.5 ((z - loc)/exp(log_scale))^2)
-                const float e0 = (z0[q] - a.base_loc[0]) / a.base_scale[0], e1 = (z1[q] - a.base_loc[1]) / a.base_scale[1];
-                const float lp = a.base_c0 - ((a.base_log_scale[0] + 0.5f * (e0 * e0)) + (a.base_log_scale[1] + 0.5f * (e1 * e1)));
-                a.log_q[row] = lq[q] + lp;
-            } else {
-                a.z_out[row] = z0[q];
-                a.z_out[a.n_rows + row] = z1[q];
-                a.log_q[row] = lq[q];
-            }
+    if constexpr (TILE_MODE) {
+        const int64_t row = wg_row0 + (int64_t)wave * 32 + col;
+        if (tile_active && row < a.n_rows && lane < 32) nf_row_store<INVERSE>(a, row, z0, z1, lq);
+    } else {
+        // the lane-derived offsets are recomputed from the thread id here (laundered through an empty asm) instead of
+        // being kept alive -- or spilled -- across the coupling loop
+        int tid = threadIdx.x;
+        __asm__ volatile("" : "+v"(tid));
+        const int lane2 = tid & 63, wave2 = tid >> 6;
+        const float* st2 = lds + NF_BLOCK_FLOATS + wave2 * a.state_floats_per_wave;
+        for (int p = wave2, slot = 0; p < n_pairs; p += NF_WAVES, ++slot) {
+            const int64_t row = wg_row0 + (int64_t)p * 64 + lane2;
+            const float* s = st2 + slot * 192 + (lane2 >> 5) * 96 + (lane2 & 31);
+            if (row < a.n_rows) nf_row_store<INVERSE>(a, row, s[0], s[32], s[64]);
         }
     }
 }
@@ -324,19 +369,20 @@ static NfArgs nf_pack(const glabc_flow* f, const float* in, float* z, float* log
     return a;
 }
 
-template <bool INV, int NP>
-static int nf_launch_np(NfArgs a, int rows_per_wg, hipStream_t s)
+template <bool INV, bool TILE>
+static int nf_launch_mode(NfArgs a, int rows_per_wg, int slots_per_wave, hipStream_t s)
 {
-    const size_t lds_bytes = sizeof(float) * NF_BLOCK_FLOATS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)nf_kernel<INV, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return GLABC_ERR_LAUNCH;
-        attr_set = true;
-    }
     a.rows_per_wg = rows_per_wg;
+    a.state_floats_per_wave = 192 * slots_per_wave;
+    const size_t lds_bytes = sizeof(float) * ((size_t)NF_BLOCK_FLOATS + (size_t)NF_WAVES * a.state_floats_per_wave);
+    static size_t attr_bytes = 0;                        // the largest dynamic LDS size this instantiation was allowed so far
+    if (lds_bytes > attr_bytes) {
+        if (hipFuncSetAttribute((const void*)nf_kernel<INV, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return GLABC_ERR_LAUNCH;
+        attr_bytes = lds_bytes;
+    }
     const unsigned grid = (unsigned)((a.n_rows + rows_per_wg - 1) / rows_per_wg);
-    hipLaunchKernelGGL((nf_kernel<INV, NP>), dim3(grid), dim3(64 * NF_WAVES), lds_bytes, s, a);
+    hipLaunchKernelGGL((nf_kernel<INV, TILE>), dim3(grid), dim3(64 * NF_WAVES), lds_bytes, s, a);
     return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
 }
 
@@ -346,9 +392,13 @@ template <bool INV>
 static int nf_launch(const NfArgs& a, hipStream_t s)
 {
     const int64_t tiles = (a.n_rows + 31) / 32;
+    if (const char* force = std::getenv("GLABC_NF_TILE_WAVES")) {          // experiment knob: tile mode, this many tiles per workgroup
+        const int w = std::atoi(force);
+        if (w >= 1 && w <= NF_WAVES) return nf_launch_mode<INV, true>(a, 32 * w, 0, s);
+    }
     // up to one tile per CU (8192 rows) the launch is a latency chain of couplings: one tile per workgroup halves it
     // against one pair per workgroup.  (With more tiles than CUs, pairs win again: 65 536 rows measured 77 vs 65 TFLOP/s.)
-    if (tiles <= (int64_t)NF_CUS) return nf_launch_np<INV, 0>(a, 32, s);
+    if (tiles <= (int64_t)NF_CUS) return nf_launch_mode<INV, true>(a, 32, 0, s);
     const int64_t pairs = (a.n_rows + 63) / 64;
     int64_t pairs_per_wg = (pairs + NF_CUS - 1) / NF_CUS;
     const int64_t cap = (int64_t)NF_WAVES * NF_MAX_PAIRS;
@@ -356,15 +406,8 @@ static int nf_launch(const NfArgs& a, hipStream_t s)
         const int64_t rounds = (pairs_per_wg + cap - 1) / cap;
         pairs_per_wg = (pairs + NF_CUS * rounds - 1) / (NF_CUS * rounds);
     }
-    const int np = (int)((pairs_per_wg + NF_WAVES - 1) / NF_WAVES);
-    const int rows_per_wg = (int)pairs_per_wg * 64;
-    switch (np) {
-    case 1: return nf_launch_np<INV, 1>(a, rows_per_wg, s);
-    case 2: return nf_launch_np<INV, 2>(a, rows_per_wg, s);
-    case 3: return nf_launch_np<INV, 3>(a, rows_per_wg, s);
-    case 4: return nf_launch_np<INV, 4>(a, rows_per_wg, s);
-    default: return nf_launch_np<INV, NF_MAX_PAIRS>(a, rows_per_wg, s);
-    }
+    const int slots = (int)((pairs_per_wg + NF_WAVES - 1) / NF_WAVES);
+    return nf_launch_mode<INV, false>(a, (int)pairs_per_wg * 64, slots, s);
 }
 
 extern "C" {

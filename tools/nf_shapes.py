@@ -7,7 +7,7 @@ from glabcmcmc_amd.flows import RealNVP
 torch.manual_seed(0)
 flow = RealNVP(8).cuda()
 blob = flow.packed_params(); f = flow.descriptor(blob); lib = _capi.lib()
-for rows in (65536, 131072, 262144, 327680, 393216, 524288, 655360, 1310720):
+for rows in (65536, 327680, 655360):
     z = torch.empty(2, rows, device="cuda"); lq = torch.empty(rows, device="cuda")
     for inverse in (False, True):
         def go():
