@@ -170,6 +170,61 @@ def bench_kde(args):
                                            "construction (~60 vector instructions per pair over two passes); see DESIGN.md 4.3"}}), flush=True)
 
 
+def bench_glmcmc_nf(args):
+    """BASELINE configs[4] end to end: GLMCMC_NF (GLMCMC_NFs.py:43-186) at 65 536 chains, RealNVP with 8 couplings, N = 5,
+    pools of step_size = 20 slices per chain, gf 0.9, one Adam step at the first pool refresh (Train_step = 1).  One bench
+    step = --iters iterations of the whole loop: pool draws through the MFMA forward kernel (amortised 5 rows per chain and
+    iteration), pool weights, the per-iteration NF-iSIR / RW-MH kernel and the log_prob refresh of the chains that moved."""
+    import glabcmcmc_amd as g
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    torch.cuda.set_device(0)
+    n, K, N, step_size = args.chains, min(args.iters, 100), NBATCH, 20
+    m = Mixture_set(EPS)
+    lp = g.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35])))
+    torch.manual_seed(0)
+    from glabcmcmc_amd.flows import RealNVP
+    flow = RealNVP(args.couplings)
+    with torch.no_grad():
+        for c in flow.couplings:
+            c.l3.weight.normal_(0, 0.3 / 128 ** 0.5)
+            c.l3.bias.normal_(0, 0.1)
+    theta0 = torch.zeros(n, 2)
+    y0 = (0.05 ** 0.5) * torch.randn(n, 2)
+    st = {}
+
+    def one_step(i):
+        g.GLMCMC_NF(m, K + 1, theta0, y0, lp, None, GF, step_size, N, None, 1 if i == 0 else 0, num_layers=args.couplings,
+                    seed=100 + i, flow=flow, return_device=True, verbose=False, state_out=st)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    per_iter = elapsed / (args.steps * K)
+    rows_per_iter = float(N) * step_size * n * st["pools_drawn"] / K   # pool rows drawn per iteration (last run)
+    moved = float(st["chains"].n_moves.double().sum()) / K            # log_prob refreshes per iteration (last run)
+    mfma_flop = 2.0 * 128 * 128 * args.couplings * (rows_per_iter + moved + n / K)
+    achieved = mfma_flop / per_iter / 1e12
+    out = {"metric": "MH accept-steps/sec, GLMCMC_NF end to end (RealNVP %d couplings), 65 536 chains" % args.couplings,
+           "value": float(n) / per_iter, "unit": "chain-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "GLMCMC_NF, %d couplings x MLP[1,128,128,2], N=5, step_size=%d, gf=0.9, Mixture_set eps=0.05 "
+                                  "(BASELINE configs[4]); host loop: 2 kernel launches per iteration + pool refreshes"
+                                  % (args.couplings, step_size), "chains_per_gpu": n, "iters_per_step": K},
+           "iterations_per_s": 1.0 / per_iter, "us_per_iteration": per_iter * 1e6,
+           "moved_chains_per_iteration": moved, "pool_rows_per_iteration": rows_per_iter, "pools_per_step": st["pools_drawn"],
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+                        "traffic": None, "kernel": "glabc::nf_kernel<forward, pairs> (pool draws)", "kernel_ms": None,
+                        "note": "whole-loop rate: MFMA flops of the pool draws + log_prob refreshes over the wall time of the "
+                                "loop (pool weights, step kernels, host launches included); the kernel alone: --workload nf"}}
+    print(json.dumps(out), flush=True)
+
+
 def bench_callback(args):
     """SURVEY.md 8b-ii, the reference's plug-in API: GLMCMC (iSIR N=5, gf 0.9) with a user Model that is a plain-torch
     object -- no descriptor, so every iteration is glabc_propose -> the Model's callbacks on a (5 * chains, 2) batch ->
@@ -279,7 +334,7 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the multi-rank control flow on ONE GPU: every rank uses cuda:0 and the collectives "
                          "run on gloo with CPU copies (numbers are meaningless; RCCL needs one GPU per rank)")
-    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback"],
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback", "glmcmc_nf"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
@@ -289,6 +344,8 @@ def main():
         return bench_kde(args)
     if args.workload == "callback":
         return bench_callback(args)
+    if args.workload == "glmcmc_nf":
+        return bench_glmcmc_nf(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

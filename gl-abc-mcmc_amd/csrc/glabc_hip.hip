@@ -236,6 +236,9 @@ struct PoolArgs {
     float* w_out;
     int64_t n_rows, row_id0;
     int32_t step_size;
+    int32_t* moved_idx;
+    int32_t* n_moved;
+    int32_t* n_moved_reset;
 };
 
 template <int D>
@@ -412,6 +415,8 @@ __global__ void __launch_bounds__(64) nf_step_kernel(const PoolArgs<D> p)
     }
     p.kk[i] = kk;
     if (a.n_moves) a.n_moves[i] = n_moves + (moved ? 1u : 0u);
+    if (p.moved_idx && moved) p.moved_idx[atomicAdd(p.n_moved, 1)] = (int32_t)i;
+    if (p.n_moved_reset && i == 0) *p.n_moved_reset = 0;
 }
 
 // ---- Gamma.log_prob, distribution.py:123-137 (float64) ----------------------------------------------------
@@ -900,6 +905,8 @@ __attribute__((visibility("default"))) int glabc_glmcmc_nf_step(const glabc_mode
     if (r->n_steps != 1 || r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH) return GLABC_ERR_ARG;
     if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
     if (r->tape || r->moments || r->global_frequency_per_chain) return GLABC_ERR_ARG;
+    if ((pool->moved_idx == nullptr) != (pool->n_moved == nullptr)) return GLABC_ERR_NULL;
+    if (c->n_chains > 0x7fffffff) return GLABC_ERR_ARG;
     if (c->n_chains == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;
 #define GLABC_NFSTEP(d)                                                       \
@@ -909,6 +916,7 @@ __attribute__((visibility("default"))) int glabc_glmcmc_nf_step(const glabc_mode
         p.s = pack_args<d>(model, local, &model->prior, c, r);                \
         p.theta = pool->theta; p.x = pool->x; p.w = pool->w; p.log_q = pool->log_q_old; p.kk = pool->kk; \
         p.step_size = pool->step_size;                                        \
+        p.moved_idx = pool->moved_idx; p.n_moved = pool->n_moved; p.n_moved_reset = pool->n_moved_reset; \
         return launch_nf_step<d>(p, r->batch_size, s);                        \
     }
     switch (model->theta_dim) {

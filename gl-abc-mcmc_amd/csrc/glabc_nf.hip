@@ -71,6 +71,10 @@ struct NfArgs {
     int64_t n_rows, row0;
     uint32_t seed_lo, seed_hi;
     int32_t rows_per_wg;          // multiple of 64 (pairs), of 32 in tile mode
+    // indexed inverse (glabc_nf_log_prob_indexed): rows are idx[0 .. *n_dev), inputs in[idx] / in[in_stride + idx]
+    const int32_t* idx;
+    const int32_t* n_dev;
+    int64_t in_stride;
     int32_t state_floats_per_wave; // pair mode: 192 floats (2 tiles x 3 x 32) per pair slot of a wave
 };
 
@@ -192,12 +196,13 @@ __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, f
 // Initial state of one row: forward = the base distribution's draw (nf.distributions.base.DiagGaussian.forward: z = loc +
 // exp(log_scale)*eps, log_p = C - sum(log_scale + 0.5 eps^2)), inverse = the point itself with log_q = 0.
 template <bool INVERSE>
-__device__ __forceinline__ void nf_row_init(const NfArgs& a, int64_t row, float& z0, float& z1, float& lq)
+__device__ __forceinline__ void nf_row_init(const NfArgs& a, int64_t n_rows, int64_t row, float& z0, float& z1, float& lq)
 {
-    const int64_t rr = row < a.n_rows ? row : a.n_rows - 1;
+    const int64_t rr = row < n_rows ? row : n_rows - 1;
     if (INVERSE) {
-        z0 = a.in[rr];
-        z1 = a.in[a.n_rows + rr];
+        const int64_t src = a.idx ? (int64_t)a.idx[rr] : rr;
+        z0 = a.in[src];
+        z1 = a.in[a.in_stride + src];
         lq = 0.0f;
         return;
     }
@@ -238,7 +243,7 @@ __device__ __forceinline__ void nf_row_store(const NfArgs& a, int64_t row, float
         // + q0.log_prob(z): C - sum(log_scale + 0.5 ((z - loc)/exp(log_scale))^2)
         const float e0 = (z0 - a.base_loc[0]) / a.base_scale[0], e1 = (z1 - a.base_loc[1]) / a.base_scale[1];
         const float lp = a.base_c0 - ((a.base_log_scale[0] + 0.5f * (e0 * e0)) + (a.base_log_scale[1] + 0.5f * (e1 * e1)));
-        a.log_q[row] = lq + lp;
+        a.log_q[a.idx ? (int64_t)a.idx[row] : row] = lq + lp;
     } else {
         a.z_out[row] = z0;
         a.z_out[a.n_rows + row] = z1;
@@ -258,18 +263,20 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31;
     const int64_t wg_row0 = (int64_t)blockIdx.x * a.rows_per_wg;
+    const int64_t n_rows = a.n_dev ? (int64_t)*a.n_dev : a.n_rows;     // indexed mode: the row count lives on the device
+    if (wg_row0 >= n_rows) return;                                     // (workgroup-uniform, before any barrier)
     const int n_pairs = a.rows_per_wg / 64;                            // pair mode: 64-row pairs in this workgroup
     float* st = lds + NF_BLOCK_FLOATS + wave * a.state_floats_per_wave;   // [slot][tile a/b][z0, z1, lq][32 rows]
 
     float z0 = 0.0f, z1 = 0.0f, lq = 0.0f;                             // tile mode only
     const bool tile_active = wave * 32 < a.rows_per_wg;                // wave-uniform
     if constexpr (TILE_MODE) {
-        if (tile_active) nf_row_init<INVERSE>(a, wg_row0 + (int64_t)wave * 32 + col, z0, z1, lq);
+        if (tile_active) nf_row_init<INVERSE>(a, n_rows, wg_row0 + (int64_t)wave * 32 + col, z0, z1, lq);
     } else {
         for (int p = wave, slot = 0; p < n_pairs; p += NF_WAVES, ++slot) {
             // lane l initialises row 64p + l of the pair: tile a = lanes 0..31, tile b = lanes 32..63
             float i0, i1, il;
-            nf_row_init<INVERSE>(a, wg_row0 + (int64_t)p * 64 + lane, i0, i1, il);
+            nf_row_init<INVERSE>(a, n_rows, wg_row0 + (int64_t)p * 64 + lane, i0, i1, il);
             float* s = st + slot * 192 + (lane >> 5) * 96 + col;
             s[0] = i0;
             s[32] = i1;
@@ -316,7 +323,7 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
 
     if constexpr (TILE_MODE) {
         const int64_t row = wg_row0 + (int64_t)wave * 32 + col;
-        if (tile_active && row < a.n_rows && lane < 32) nf_row_store<INVERSE>(a, row, z0, z1, lq);
+        if (tile_active && row < n_rows && lane < 32) nf_row_store<INVERSE>(a, row, z0, z1, lq);
     } else {
         // the lane-derived offsets are recomputed from the thread id here (laundered through an empty asm) instead of
         // being kept alive -- or spilled -- across the coupling loop
@@ -327,7 +334,7 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
         for (int p = wave2, slot = 0; p < n_pairs; p += NF_WAVES, ++slot) {
             const int64_t row = wg_row0 + (int64_t)p * 64 + lane2;
             const float* s = st2 + slot * 192 + (lane2 >> 5) * 96 + (lane2 & 31);
-            if (row < a.n_rows) nf_row_store<INVERSE>(a, row, s[0], s[32], s[64]);
+            if (row < n_rows) nf_row_store<INVERSE>(a, row, s[0], s[32], s[64]);
         }
     }
 }
@@ -363,6 +370,7 @@ static NfArgs nf_pack(const glabc_flow* f, const float* in, float* z, float* log
     a.z_out = z;
     a.log_q = log_q;
     a.n_rows = n;
+    a.in_stride = n;
     a.row0 = row0;
     a.seed_lo = (uint32_t)seed;
     a.seed_hi = (uint32_t)(seed >> 32);
@@ -430,6 +438,24 @@ __attribute__((visibility("default"))) int glabc_nf_log_prob(const glabc_flow* f
     if (!x) return GLABC_ERR_NULL;
     if (n_rows == 0) return GLABC_OK;
     return nf_launch<true>(nf_pack(flow, x, nullptr, log_q, n_rows, 0, 0), (hipStream_t)stream);
+}
+
+__attribute__((visibility("default"))) int glabc_nf_log_prob_indexed(const glabc_flow* flow, const float* theta, int64_t stride,
+                                                                     const int32_t* idx, const int32_t* n_dev, int64_t max_rows,
+                                                                     float* log_q, void* stream)
+{
+    int rc = nf_check(flow, theta, log_q, max_rows);
+    if (rc) return rc;
+    if (!theta || !idx || !n_dev) return GLABC_ERR_NULL;
+    if (stride < max_rows) return GLABC_ERR_ARG;
+    if (max_rows == 0) return GLABC_OK;
+    NfArgs a = nf_pack(flow, theta, nullptr, log_q, max_rows, 0, 0);
+    a.in_stride = stride;
+    a.idx = idx;
+    a.n_dev = n_dev;
+    // one 32-row tile per workgroup: the moved chains of an iteration are a few per cent of the chains, so the launch is a
+    // latency chain of couplings on a few dozen CUs; workgroups past the device-side count return at once
+    return nf_launch_mode<true, true>(a, 32, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"

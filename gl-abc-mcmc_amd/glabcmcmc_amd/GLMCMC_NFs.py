@@ -7,8 +7,11 @@ Same positional signature as the reference function (``base`` is accepted for si
 
 * pool draw  ``NF_model.sample(batch_size*step_size)`` per chain  -> ``glabc_nf_sample`` (f32 MFMA), GLMCMC_NFs.py:70-72
 * pool weights (simulate, prior, kernel, exp)                     -> ``glabc_pool_weights``,        :73-85
-* per iteration: ``NF_model.log_prob(Theta_old)``                  -> ``glabc_nf_log_prob`` (f32 MFMA), :96-98
-                 iSIR against the next pool slice / RW-MH          -> ``glabc_glmcmc_nf_step``,        :92-111,141-152
+* per iteration: iSIR against the next pool slice / RW-MH          -> ``glabc_glmcmc_nf_step``,        :92-111,141-152
+                 ``NF_model.log_prob(Theta_old)`` (:96-98) is a pure function of the state and the flow: it is kept per
+                 chain and re-evaluated only for the chains that moved (``glabc_nf_log_prob_indexed``, f32 MFMA, the list
+                 and its length stay on the device) and for all chains after an optimizer step -- same values, a few per
+                 cent of the work
 * when a pool is used up: at most ``Train_step`` Adam steps on the forward KL of a systematically resampled pool
   (:112-124, ``resample`` :29-40) -- stock PyTorch autograd on the same device -- then a new pool (:125-140).
 
@@ -77,8 +80,16 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     refresh, num_train = 0, 0
     draw_pool(refresh)
     log_q_old = torch.empty(n, dtype=torch.float32, device=dev)
+    moved_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+    n_moved = torch.zeros(2, dtype=torch.int32, device=dev)                                        # counters of odd / even iterations
     blob = flow.packed_params()                                                                    # repacked only after an optimizer step
     fdesc = flow.descriptor(blob)
+
+    def log_prob_all():                                                                            # :96-98 for every chain
+        with torch.cuda.device(dev):
+            _capi.check(lib.glabc_nf_log_prob(C.byref(fdesc), chains.theta.data_ptr(), n, log_q_old.data_ptr(), stream),
+                        "glabc_nf_log_prob")
+    log_prob_all()
     # a chain uses at most one pool slice per iteration, so the pools cannot run out before `countdown` more
     # iterations: the device is only asked (a sync) when that is possible -- same schedule as checking every iteration
     countdown = int(step_size)
@@ -86,15 +97,17 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     run = _capi.Run()
     run.seed, run.n_steps, run.global_frequency, run.batch_size, run.hist_stride = key, 1, float(global_frequency), N, n
     hist_ptr, hist_row_bytes = hist.data_ptr(), hist[0].numel() * 4
+    cnt = [n_moved[0:].data_ptr(), n_moved[1:].data_ptr()]
     for i in range(1, num_ite):
         with torch.cuda.device(dev):
-            _capi.check(lib.glabc_nf_log_prob(C.byref(fdesc), chains.theta.data_ptr(), n, log_q_old.data_ptr(), stream),
-                        "glabc_nf_log_prob")                                                       # :96-98
             pd = _capi.Pool(pool["theta"].data_ptr(), pool["x"].data_ptr(), pool["w"].data_ptr(), log_q_old.data_ptr(),
-                            kk.data_ptr(), int(step_size), 0)
+                            kk.data_ptr(), int(step_size), 0, moved_idx.data_ptr(), cnt[i & 1], cnt[(i + 1) & 1])
             run.step0, run.history = i, hist_ptr + i * hist_row_bytes
             _capi.check(lib.glabc_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pd), C.byref(cs), C.byref(run),
                                                  stream), "glabc_glmcmc_nf_step")
+            _capi.check(lib.glabc_nf_log_prob_indexed(C.byref(fdesc), chains.theta.data_ptr(), n, moved_idx.data_ptr(),
+                                                      cnt[i & 1], n, log_q_old.data_ptr(), stream),
+                        "glabc_nf_log_prob_indexed")                                               # :96-98 for the chains that moved
         countdown -= 1
         if countdown > 0:
             continue
@@ -117,9 +130,10 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
             losses.append(float(loss.detach()))
             blob = flow.packed_params()
             fdesc = flow.descriptor(blob)
+            log_prob_all()                                                                         # the flow changed under every chain
         refresh += 1
         draw_pool(refresh)                                                                         # :125-140
         countdown = int(step_size)
     if state_out is not None:
-        state_out.update(chains=chains, flow=flow, loss_hist=losses, num_train=num_train)
+        state_out.update(chains=chains, flow=flow, loss_hist=losses, num_train=num_train, pools_drawn=refresh + 1)
     return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)

@@ -116,6 +116,9 @@ class Pool(C.Structure):
         ("kk", C.c_void_p),
         ("step_size", C.c_int32),
         ("reserved", C.c_int32),
+        ("moved_idx", C.c_void_p),
+        ("n_moved", C.c_void_p),
+        ("n_moved_reset", C.c_void_p),
     ]
 
 
@@ -221,6 +224,8 @@ ENTRY_POINTS = {
     "glabc_glmala_init": (C.c_int, [_P(Model), _P(Chains), C.c_void_p]),
     "glabc_nf_sample": (C.c_int, [_P(Flow), C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "glabc_nf_log_prob": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_nf_log_prob_indexed": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                            C.c_void_p]),
     "glabc_pool_weights": (C.c_int, [_P(Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "glabc_glmcmc_nf_step": (C.c_int, [_P(Model), _P(Dist), _P(Pool), _P(Chains), _P(Run), C.c_void_p]),

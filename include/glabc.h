@@ -233,6 +233,12 @@ int glabc_nf_sample(const glabc_flow* flow, const float* eps, uint64_t seed, int
 /* NF_model.log_prob(x): x pulled back through the couplings in reverse order (inverse pass) + base log_prob. */
 int glabc_nf_log_prob(const glabc_flow* flow, const float* x, int64_t n_rows, float* log_q, void* stream);
 
+/* NF_model.log_prob for the rows listed in idx[0 .. *n_dev - 1] only: x = (theta[idx], theta[stride + idx]) (the chain-major
+ * state arrays), result to log_q[idx].  *n_dev is read on the device (no host synchronisation); max_rows bounds it (the grid).
+ * Same arithmetic per row as glabc_nf_log_prob. */
+int glabc_nf_log_prob_indexed(const glabc_flow* flow, const float* theta, int64_t stride, const int32_t* idx,
+                              const int32_t* n_dev, int64_t max_rows, float* log_q, void* stream);
+
 /* ---- GLMCMC_NF (GLMCMC_NFs.py:43-186): iSIR against a pool of flow proposals -----------------------------
  * A pool holds P = batch_size*step_size proposals per chain, row r = p*n_chains + c (slice kk of chain c =
  * rows p in [kk*batch_size, (kk+1)*batch_size)), arrays chain-major [dim][P*n_chains].
@@ -255,6 +261,12 @@ typedef struct glabc_pool {
     int32_t* kk;                   /* [n_chains] slices already consumed, GLMCMC_NFs.py:86,111 */
     int32_t step_size;             /* slices per pool */
     int32_t reserved;
+    /* optional (all three NULL or moved_idx + n_moved set): the chains that moved in this iteration, so that the caller
+     * re-evaluates NF_model.log_prob(Theta_old) (GLMCMC_NFs.py:96-98, a pure function of the state and the flow) only for
+     * them -- glabc_nf_log_prob_indexed.  The order of the list is unspecified. */
+    int32_t* moved_idx;            /* [n_chains] local chain indices, entries 0 .. *n_moved - 1 */
+    int32_t* n_moved;              /* device counter, incremented atomically; the caller or n_moved_reset zeroes it */
+    int32_t* n_moved_reset;        /* NULL or a counter this call sets to 0 (the one the NEXT iteration will count into) */
 } glabc_pool;
 
 int glabc_glmcmc_nf_step(const glabc_model* model, const glabc_dist* local, const glabc_pool* pool,

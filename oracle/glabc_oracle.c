@@ -1402,7 +1402,9 @@ ORACLE_API int oracle_glmcmc_nf_step(const glabc_model* m, const glabc_dist* loc
         for (int j = 0; j < yd; ++j) c->y[j * c->stride + i] = s.y[j];
         if (c->n_moves) c->n_moves[i] = s.n_moves;
         pool->kk[i] = kk;
+        if (pool->moved_idx && moved) pool->moved_idx[(*pool->n_moved)++] = (int32_t)i;
     }
+    if (pool->n_moved_reset) *pool->n_moved_reset = 0;
     return 0;
 }
 

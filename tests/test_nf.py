@@ -186,3 +186,66 @@ def test_glmcmc_nf_end_to_end(hip):
     one = g.GLMCMC_NF(m, 30, torch.tensor([0.0, 0.0]), torch.tensor([[1.5, 1.5]]), lp, None, 0.5, 3, 5, None, 2,
                       num_layers=2, seed=2, verbose=False)
     assert one.shape == (30, 2) and one.device.type == "cpu"
+
+
+@pytest.mark.gpu
+def test_log_prob_cache_follows_the_moved_chains(hip, oracle):
+    """GLMCMC_NF keeps NF_model.log_prob(Theta_old) (GLMCMC_NFs.py:96-98) per chain and refreshes it only for the chains
+    glabc_glmcmc_nf_step reports as moved (glabc_nf_log_prob_indexed, count read on the device): after every iteration the
+    cache must equal, bit for bit, a from-scratch evaluation of all current states, and the moved list must be the oracle's."""
+    import oracle_lib
+    from glabcmcmc_amd import engine
+    model, local, _ = _mix_descs()
+    flow = make_flow(3, 21)
+    fh, blob_h = host_descriptor(flow)
+    fg_blob = flow.packed_params().cuda()
+    fg = flow.descriptor(fg_blob)
+    rng = np.random.default_rng(4)
+    n, N, step_size, gf = 1500, 4, 6, 0.7
+    rows = N * step_size * n
+    theta = (rng.standard_normal((2, rows)) * 1.3).astype(np.float32)
+    x = (np.abs(theta) + 0.2236 * rng.standard_normal((2, rows))).astype(np.float32)
+    w = np.exp(rng.standard_normal(rows)).astype(np.float32)
+    tg, xg, wg = (torch.from_numpy(a).cuda() for a in (theta, x, w))
+    theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+    y0 = np.abs(theta0).astype(np.float32)
+    hc = oracle_lib.HostChains(theta0, y0, chain0=3, with_isir=False)
+    gc = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), torch.device("cuda", 0), chain0=3)
+    kk_h, kk_g = np.zeros(n, np.int32), torch.zeros(n, dtype=torch.int32, device="cuda")
+    moved_h, n_moved_h = np.zeros(n, np.int32), np.zeros(1, np.int32)
+    moved_g = torch.zeros(n, dtype=torch.int32, device="cuda")
+    n_moved_g = torch.zeros(2, dtype=torch.int32, device="cuda")
+
+    def full_log_prob(theta_cm):
+        out = np.empty(n, np.float32)
+        assert oracle.oracle_nf_log_prob(C.byref(fh), np.ascontiguousarray(theta_cm).ctypes.data, n, out.ctypes.data) == 0
+        return out
+
+    cache = torch.empty(n, dtype=torch.float32, device="cuda")
+    assert hip.glabc_nf_log_prob(C.byref(fg), gc.theta.data_ptr(), n, cache.data_ptr(), None) == 0
+    total = 0
+    for it in range(1, step_size + 3):
+        lqo = full_log_prob(hc.theta)
+        assert np.array_equal(bits(cache.cpu().numpy()), bits(lqo)), it
+        n_moved_h[0] = 0
+        pool_h = A.Pool(theta.ctypes.data, x.ctypes.data, w.ctypes.data, lqo.ctypes.data, kk_h.ctypes.data, step_size, 0,
+                        moved_h.ctypes.data, n_moved_h.ctypes.data, None)
+        run_h, keep = oracle_lib.make_run(seed=8, step0=it, n_steps=1, gf=gf, batch=N)
+        cs = hc.struct()
+        assert oracle.oracle_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pool_h), C.byref(cs), C.byref(run_h)) == 0
+        cur, nxt = n_moved_g[it & 1:], n_moved_g[(it + 1) & 1:]
+        pool_g = A.Pool(tg.data_ptr(), xg.data_ptr(), wg.data_ptr(), cache.data_ptr(), kk_g.data_ptr(), step_size, 0,
+                        moved_g.data_ptr(), cur.data_ptr(), nxt.data_ptr())
+        run_g = A.Run()
+        run_g.seed, run_g.step0, run_g.n_steps, run_g.global_frequency, run_g.batch_size = 8, it, 1, gf, N
+        csg = gc.struct()
+        assert hip.glabc_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pool_g), C.byref(csg), C.byref(run_g), None) == 0
+        assert hip.glabc_nf_log_prob_indexed(C.byref(fg), gc.theta.data_ptr(), n, moved_g.data_ptr(), cur.data_ptr(), n,
+                                             cache.data_ptr(), None) == 0
+        k = int(cur[0].item())
+        assert k == int(n_moved_h[0]) and int(nxt[0].item()) == 0
+        assert np.array_equal(np.sort(moved_g[:k].cpu().numpy()), np.sort(moved_h[:k]))
+        assert np.array_equal(bits(gc.theta.cpu().numpy()), bits(hc.theta))
+        total += k
+    assert total > n // 2
+    assert np.array_equal(bits(cache.cpu().numpy()), bits(full_log_prob(hc.theta)))
