@@ -22,6 +22,7 @@ refreshed together as soon as one chain has used its ``step_size`` slices, and t
 ``max_train`` pool rows (rows are slice-major, so every chain contributes).  With C = 1 this is the reference's schedule.
 """
 import ctypes as C
+import warnings
 
 import numpy as np
 import torch
@@ -36,7 +37,7 @@ ISIR_STREAM, POOL_STREAM, KDE_STREAM = 0x9E3779B97F4A7C15, 0x5851F42D4C957F2D, 0
 
 def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_ISIR_prop,
             filelocation, global_frequency, step_size, batch_size, alpha, hat_eps_T, device=None, *,
-            seed=None, chain0=0, return_device=False, verbose=True, max_train=8192, state_out=None):
+            seed=None, chain0=0, return_device=False, verbose=True, max_train=None, state_out=None):
     lib = _capi.lib()
     model = engine.model_descriptor(ABCset)
     local = Local_Proposal.descriptor()
@@ -76,6 +77,7 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
 
     KDE = None
     kde_rows = [0]
+    warned = []
     num_train, eps_num = 0, 0
     hat_eps = 1000000.0                                                                           # :119
     log_q_old = torch.empty(n, dtype=torch.float32, device=dev)
@@ -123,7 +125,14 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
         with torch.cuda.device(dev):
             _capi.check(lib.glabc_kde_train_weights(C.byref(train_model), pool["theta"].data_ptr(), dis0.data_ptr(),
                                                     pool["lq"].data_ptr(), rows, tw.data_ptr(), stream), "glabc_kde_train_weights")
-        m = min(rows, int(max_train))
+        # the reference trains its KDE on all batch_size*step_size pool rows (AGLMCMC.py:199-215): with one chain that is
+        # what happens here (max_train None); a batch of chains shares ONE density, whose O(points x centres) evaluation is
+        # capped at 8192 centres unless the caller asks for more
+        cap = rows if (max_train is None and n == 1) else int(8192 if max_train is None else max_train)
+        if cap < rows and not warned:
+            warned.append(True)
+            warnings.warn('AGLMCMC: the adaptive KDE is trained on the first %d of %d pool rows (max_train)' % (cap, rows))
+        m = min(rows, cap)
         keep = tw[:m] > 0                                                                         # :207-208
         if bool(keep.any()):
             KDE = KernelDensity(bandwidth='silverman', device=dev, seed=key ^ KDE_STREAM)
@@ -151,4 +160,4 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
         weigh_pool(theta_new, KDE.log_prob_soa(theta_new))                                        # :229-249
     if state_out is not None:
         state_out.update(chains=chains, kde=KDE, hat_eps=hat_eps, num_train=num_train, eps_num=eps_num, pool=pool)
-    return _host.finish(hist, chains, single, filelocation, "glmcmc", verbose and single, return_device)
+    return _host.finish(hist, chains, single, filelocation, "aglmcmc", verbose and single, return_device)

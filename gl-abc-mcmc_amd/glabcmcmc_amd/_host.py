@@ -57,12 +57,22 @@ def write_csv(Theta_Re, filelocation, variant):
     every 10 000 iterations and at the end.  variant 'glmcmc' is GLMCMC.py:105-111
     (k = (i-1)//10000); variant 'global' is GlobalMCMC.py:70-76 == GLMALA.py:201-207 ==
     GLMCMC_NFs.py:153-159 (k = i//10000, start (k-1)*10000+1), which re-writes the previous
-    block at the tail -- reproduced, since downstream scripts read the file as written."""
+    block at the tail -- reproduced, since downstream scripts read the file as written.  variant 'aglmcmc' is
+    AGLMCMC.py:275-288: blocks of 10 000 rows while the loop runs, the tail after it -- and nothing at all for the last
+    block when num_ite - 1 is a multiple of 10 000 (neither clause fires; reproduced as well)."""
     num_ite = Theta_Re.shape[0]
     rows = Theta_Re.numpy()
     with open(filelocation, "w", newline="", encoding="utf-8") as f:
         w = csv.writer(f)
         w.writerow(rows[0])
+        if variant == "aglmcmc":
+            for i in range(1, num_ite):
+                if i % 10000 == 0 and i + 1 < num_ite:                          # AGLMCMC.py:276-280
+                    w.writerows(rows[max(1, (i // 10000 - 1) * 10000 + 1):i + 1])
+            i = num_ite - 1
+            if i >= 1 and i % 10000 != 0:                                       # AGLMCMC.py:283-288
+                w.writerows(rows[max(1, (i // 10000) * 10000 + 1):i + 1])
+            return
         for i in range(1, num_ite):
             if i % 10000 == 0 or i == num_ite - 1:
                 if variant == "glmcmc":

@@ -29,7 +29,7 @@ def save(path, chains, seed, next_step, moments=None, extra=None):
 def load(path, device=None):
     """-> (chains, seed, next_step, moments or None, extra)"""
     dev = engine.require_device(device)
-    state = torch.load(path, map_location="cpu", weights_only=False)
+    state = torch.load(path, map_location="cpu", weights_only=True)      # tensors, numbers, strings, dicts only
     chains = engine.ChainBatch.__new__(engine.ChainBatch)
     chains.device, chains.n, chains.d, chains.yd, chains.chain0 = dev, state["n"], state["d"], state["yd"], state["chain0"]
     for f in _FIELDS:

@@ -56,25 +56,28 @@ def stream_history(entry, model_desc, local_desc, global_desc, chains, n_steps, 
     th.start()
     compute = torch.cuda.current_stream(dev)
     done, i = 0, 0
-    while done < n_steps:
-        b = i & 1
-        rows = min(k, n_steps - done)
-        compute.wait_event(copied[b])                          # the copy that last read dev_blocks[b] is over
-        engine.run_steps(entry, model_desc, local_desc, global_desc, chains, rows, step0 + done, seed, global_frequency,
-                         batch_size, history=dev_blocks[b], moments=moments, steps_per_launch=rows)
-        filled[b].record(compute)
-        host_free[b].wait()                                    # the writer is done with host_blocks[b]
-        host_free[b].clear()
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(filled[b])
-            host_blocks[b][:rows].copy_(dev_blocks[b][:rows], non_blocking=True)
-            copied[b].record(copy_stream)
-        work.put((b, done, rows))
-        done += rows
-        i += 1
-    work.put(None)
-    th.join()
-    out.close()
+    try:
+        while done < n_steps:
+            b = i & 1
+            rows = min(k, n_steps - done)
+            compute.wait_event(copied[b])                      # the copy that last read dev_blocks[b] is over
+            engine.run_steps(entry, model_desc, local_desc, global_desc, chains, rows, step0 + done, seed, global_frequency,
+                             batch_size, history=dev_blocks[b], moments=moments, steps_per_launch=rows)
+            filled[b].record(compute)
+            host_free[b].wait()                                # the writer is done with host_blocks[b]
+            host_free[b].clear()
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(filled[b])
+                host_blocks[b][:rows].copy_(dev_blocks[b][:rows], non_blocking=True)
+                copied[b].record(copy_stream)
+            work.put((b, done, rows))
+            done += rows
+            i += 1
+    finally:
+        # also when a launch raises: stop the writer thread and close the file
+        work.put(None)
+        th.join()
+        out.close()
     if errors:
         raise errors[0]
     return shape
