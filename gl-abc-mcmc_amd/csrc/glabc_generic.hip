@@ -36,94 +36,6 @@ struct GenDist {
     float p0[GD], p1[GD], p2[GD];
 };
 
-// torch.sum over a short register row t[0..n), n <= 8 (distribution.py:172,180) -- the association of aten_rowsum<N>
-// (glabc_device.h) spelled with predicates so that t is only ever indexed statically
-GLABC_DEV float rowsum_small(const float (&t)[GD], int n)
-{
-    if (n < 4) {
-        float s = t[0];
-        if (n > 1) s = s + t[1];
-        if (n > 2) s = s + t[2];
-        return s;
-    }
-    if (n < 8) {
-        float l0 = t[0];
-        if (n > 4) l0 = l0 + t[4];
-        if (n > 5) l0 = l0 + t[5];
-        if (n > 6) l0 = l0 + t[6];
-        return ((l0 + t[1]) + t[2]) + t[3];
-    }
-    float fa = 0.0f;                                  // one 8-wide vector: the eight partials added in order
-#pragma unroll
-    for (int k = 0; k < 8; ++k) fa = fa + t[k];
-    return fa;
-}
-
-GLABC_DEV int ceil_log2_i(int x)                      // c10 utils::CeilLog2
-{
-    if (x <= 2) return 1;
-    return 32 - __builtin_clz((unsigned)(x - 1));
-}
-
-// One accumulator lane of ATen's multi_row_sum (aten/src/ATen/native/cpu/SumKernel.cpp): s(0..G) summed into four cascade
-// levels -- every 2^lp additions level 0 is folded into level 1, every 2^(2 lp) level 1 into level 2, ... -- lp =
-// max(4, CeilLog2(G)/4).  For G < 16 this is the plain sequential sum.
-template <typename F>
-GLABC_DEV float cascade_lane(F s, int G)
-{
-    const int lp = ceil_log2_i(G) / 4 > 4 ? ceil_log2_i(G) / 4 : 4;
-    const int step = 1 << lp, mask = step - 1;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int i = 0;
-    while (i + step <= G) {
-        for (int j = 0; j < step; ++j, ++i) a0 = a0 + s(i);
-        a1 = a1 + a0;
-        a0 = 0.0f;
-        if ((i & (mask << lp)) != 0) continue;
-        a2 = a2 + a1;
-        a1 = 0.0f;
-        if ((i & (mask << (2 * lp))) != 0) continue;
-        a3 = a3 + a2;
-        a2 = 0.0f;
-    }
-    for (; i < G; ++i) a0 = a0 + s(i);
-    a0 = a0 + a1;
-    a0 = a0 + a2;
-    a0 = a0 + a3;
-    return a0;
-}
-
-// torch.sum over a contiguous float32 row x(0..n) of ANY length, as the reference's torch build associates it (probed for
-// n up to 20 000, tests/golden/primitives.npz rowsum_*): n < 8 -> four scalar lanes; n >= 8 -> 8-wide vectors dealt to four
-// accumulators (vector v -> accumulator v % 4 within the full groups of four, cascade levels inside each accumulator, the
-// nv % 4 leftover vectors into accumulator 0), accumulators combined left to right, then a scalar takes the n % 8 tail in
-// order followed by the eight vector partials in order.  Same results as the compile-time aten_rowsum<N> (glabc_device.h).
-template <typename F>
-GLABC_DEV float aten_rowsum_rt(F x, int n)
-{
-    if (n < 8) {
-        if (n < 4) {
-            float s = x(0);
-            for (int i = 1; i < n; ++i) s = s + x(i);
-            return s;
-        }
-        float l0 = x(0);
-        for (int i = 4; i < n; ++i) l0 = l0 + x(i);
-        return ((l0 + x(1)) + x(2)) + x(3);
-    }
-    const int nv = n / 8, G = nv / 4;
-    float fa = 0.0f;
-    for (int i = 8 * nv; i < n; ++i) fa = fa + x(i);
-    for (int k = 0; k < 8; ++k) {
-        float p[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) p[q] = cascade_lane([&](int i) { return x(8 * (4 * i + q) + k); }, G);
-        for (int v = 4 * G; v < nv; ++v) p[0] = p[0] + x(8 * v + k);
-        fa = fa + (((p[0] + p[1]) + p[2]) + p[3]);
-    }
-    return fa;
-}
-
 // DiagGaussian.log_prob / Uniform.log_prob (distribution.py:176-181, 81-86) at a point held in registers
 GLABC_DEV float gen_log_prob(const GenDist& g, const float (&z)[GD])
 {

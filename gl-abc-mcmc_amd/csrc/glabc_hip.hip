@@ -631,8 +631,13 @@ static int check_run(const glabc_model* m, const glabc_dist* local, const glabc_
     if (c->n_chains < 0 || c->stride < c->n_chains || c->chain0 < 0) return GLABC_ERR_ARG;
     if (r->n_steps < 0) return GLABC_ERR_ARG;
     if (!(r->global_frequency >= 0.0f) && !(r->global_frequency < 0.0f)) return GLABC_ERR_ARG;    // NaN
-    if (isir && (r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH)) return GLABC_ERR_ARG;
-    if (r->lanes_per_chain != 0 && r->lanes_per_chain != 1 && r->lanes_per_chain != 2 && r->lanes_per_chain != 4)
+    if (isir && (r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH_WIDE)) return GLABC_ERR_ARG;
+    if (isir && r->batch_size > GLABC_MAX_BATCH) {               // the wide kernel: 8..64 lanes per chain, Philox only
+        if (r->tape) return GLABC_ERR_ARG;
+        if (r->lanes_per_chain != 0 && r->lanes_per_chain != 8 && r->lanes_per_chain != 16 && r->lanes_per_chain != 32 &&
+            r->lanes_per_chain != 64)
+            return GLABC_ERR_ARG;
+    } else if (r->lanes_per_chain != 0 && r->lanes_per_chain != 1 && r->lanes_per_chain != 2 && r->lanes_per_chain != 4)
         return GLABC_ERR_ARG;
     if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
     if (r->moments && (!r->moments->sum_theta || !r->moments->sum_outer || !r->moments->sum_jump)) return GLABC_ERR_NULL;
@@ -669,6 +674,16 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
     if (rc) return rc;
     if (c->n_chains == 0 || r->n_steps == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (algo == ALGO_GLMCMC && r->batch_size > GLABC_MAX_BATCH) {            // glabc_wide.hip
+        if (m->sim_kind == GLABC_SIM_GK) return launch_wide<4, 8>(pack_args<4, 8>(m, local, global, c, r), r->batch_size, r->lanes_per_chain, s);
+        switch (m->theta_dim) {
+        case 1: return launch_wide<1, 1>(pack_args<1>(m, local, global, c, r), r->batch_size, r->lanes_per_chain, s);
+        case 2: return launch_wide<2, 2>(pack_args<2>(m, local, global, c, r), r->batch_size, r->lanes_per_chain, s);
+        case 3: return launch_wide<3, 3>(pack_args<3>(m, local, global, c, r), r->batch_size, r->lanes_per_chain, s);
+        case 4: return launch_wide<4, 4>(pack_args<4>(m, local, global, c, r), r->batch_size, r->lanes_per_chain, s);
+        default: return GLABC_ERR_DIM;
+        }
+    }
     const int lanes = (algo == ALGO_GLMCMC && !r->tape) ? pick_lanes(r->lanes_per_chain, r->batch_size, c->n_chains) : 1;
     // Two builds of the same kernels: up to two waves per SIMD (131 072 lanes on this part) a launch is latency-bound
     // and runs the max-ilp schedule (217 VGPRs, 6 % faster at 65 536 chains); larger launches need the occupancy

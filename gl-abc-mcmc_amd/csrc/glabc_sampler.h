@@ -124,4 +124,9 @@ constexpr int SCHED_DEFAULT = 0, SCHED_ILP = 1;
 template <int D, int YD, int SCHED>
 int launch_sampler_dim(int algo, int n_batch, int lanes, const StepArgs<D, YD>& a, hipStream_t stream);
 
+// GLMCMC with batch_size > GLABC_MAX_BATCH: lane groups of one wavefront share a chain's proposals (glabc_wide.hip).
+// lanes = 0 (choose) or 8 / 16 / 32 / 64.
+template <int D, int YD>
+int launch_wide(const StepArgs<D, YD>& a, int n_batch, int lanes, hipStream_t stream);
+
 }  // namespace glabc

@@ -16,7 +16,7 @@ offset in a multi-GPU run), ``record_history`` (False: return None, keep only
 ``return_device`` (leave the result on the GPU), ``steps_per_launch``, ``verbose``.
 
 Dispatch (``path``): a Model and proposals that describe themselves (``descriptor()``; theta_dim 1..4 or the g-and-k
-shape; batch_size <= 16) run in the fused kernel; ANY other Model object implementing the reference's callbacks
+shape; batch_size <= 4096) run in the fused kernels (above 16 proposals lane groups of a wavefront share a chain); ANY other Model object implementing the reference's callbacks
 (``generate_samples / prior_log_prob / calculate_log_kernel``, examples/Mixture.py:5-53), any theta_dim, any batch_size
 and any proposal object run through the split-phase path of ``generic.py`` (``glabc_propose`` -> callbacks ->
 ``glabc_select``).  ``path="generic"`` forces the latter; ``path="fused"`` raises instead of falling back.
@@ -34,7 +34,7 @@ def GLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     if path not in ("auto", "fused", "generic"):
         raise ValueError("path must be 'auto', 'fused' or 'generic'")
     if path == "generic" or (path == "auto" and not generic.fused_supported(ABCset, (Local_Proposal, Importance_Proposal),
-                                                                             batch_size)):
+                                                                             batch_size, _capi.MAX_BATCH_WIDE)):
         return generic.run(_capi.ALGO_GLMCMC, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Importance_Proposal,
                            filelocation, global_frequency, batch_size, "glmcmc", seed=seed, device=device, chain0=chain0,
                            record_history=record_history, stats=stats, return_device=return_device, verbose=verbose,

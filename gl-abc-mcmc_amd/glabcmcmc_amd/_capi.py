@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 MAX_DIM = 8
-MAX_BATCH = 16
+MAX_BATCH = 16            # register kernels (and every sampler but GLMCMC)
+MAX_BATCH_WIDE = 4096      # glabc_glmcmc_steps: lane groups of a wavefront share a chain's proposals
 
 DIST_DIAG_GAUSS = 0
 DIST_UNIFORM = 1

@@ -52,7 +52,7 @@ def dist_descriptor(obj, dim):
     return d
 
 
-def fused_supported(ABCset, proposals, batch_size):
+def fused_supported(ABCset, proposals, batch_size, max_batch=None):
     """Can the fused kernels (glabc_glmcmc_steps / glabc_globalmcmc_steps / glabc_glmala_steps) run this configuration?"""
     m = try_descriptor(ABCset)
     if m is None or not isinstance(m, _capi.Model):
@@ -63,7 +63,7 @@ def fused_supported(ABCset, proposals, batch_size):
             return False
     if m.sim_kind == _capi.SIM_ABS_GAUSS and not 1 <= m.theta_dim <= 4:
         return False                                         # the fused kernels are instantiated for theta_dim 1..4
-    return batch_size is None or 1 <= int(batch_size) <= _capi.MAX_BATCH
+    return batch_size is None or 1 <= int(batch_size) <= (max_batch or _capi.MAX_BATCH)
 
 
 class ModelCallbacks:

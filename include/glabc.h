@@ -41,7 +41,8 @@ extern "C" {
 
 #define GLABC_VERSION 100          /* 0.1.0 */
 #define GLABC_MAX_DIM 8            /* theta_dim, y_dim, distribution dim */
-#define GLABC_MAX_BATCH 16         /* iSIR proposals per step held in registers */
+#define GLABC_MAX_BATCH 16         /* iSIR proposals per step held in registers (one to four lanes per chain) */
+#define GLABC_MAX_BATCH_WIDE 4096  /* glabc_glmcmc_steps beyond that: 8 to 64 lanes of a wavefront share a chain's proposals */
 
 typedef enum glabc_status {
     GLABC_OK = 0,
@@ -152,13 +153,14 @@ typedef struct glabc_run {
                                       loop variable i starts at 1: GLMCMC.py:58); Philox counter word 2 */
     int32_t n_steps;               /* iterations fused into this launch (K) */
     float global_frequency;        /* GLMCMC.py:59 */
-    int32_t batch_size;            /* iSIR proposals N, GLMCMC.py:66 (1..GLABC_MAX_BATCH); ignored by GlobalMCMC */
+    int32_t batch_size;            /* iSIR proposals N, GLMCMC.py:66: 1..GLABC_MAX_BATCH_WIDE for glabc_glmcmc_steps (no tape above
+                                      GLABC_MAX_BATCH), 1..GLABC_MAX_BATCH for the other samplers; ignored by GlobalMCMC */
     float* history;                /* NULL or [n_steps][theta_dim][hist_stride]: Theta_Re rows i=step0.. GLMCMC.py:89,104 */
     int64_t hist_stride;           /* >= n_chains */
     const glabc_moments* moments;  /* NULL or accumulators (same stride as chains) */
     const glabc_tape* tape;        /* NULL = Philox */
-    int32_t lanes_per_chain;       /* launch geometry only, never changes results: 0 = choose from n_chains,
-                                      or 1 / 2 / 4 lanes cooperating on one chain's batch_size proposals */
+    int32_t lanes_per_chain;       /* launch geometry only, never changes results: 0 = choose, or 1 / 2 / 4 lanes cooperating on
+                                      one chain's batch_size proposals (8 / 16 / 32 / 64 when batch_size > GLABC_MAX_BATCH) */
     int32_t debug_flags;           /* 0, or GLABC_DEBUG_* bits: execution strategy only, never changes results */
     const float* global_frequency_per_chain;   /* NULL, or device array [n_chains] that replaces global_frequency chain by
                                       chain -- a hyper-parameter grid (examples/Mixture_hyper.py:24) is then one launch.

@@ -367,8 +367,26 @@ typedef struct step_draws {
     float u_branch;                                 /* torch.rand(1)            GLMCMC.py:59 */
     float u_accept;                                 /* torch.rand(1)            GLMCMC.py:98 */
     double u_resample;                              /* np.random.uniform(0,1)   GLMCMC.py:17 */
-    float z[GLABC_MAX_BATCH][2 * GLABC_MAX_DIM];    /* per proposal: d proposal draws then y_dim simulator draws */
+    float (*z)[2 * GLABC_MAX_DIM];                  /* per proposal: d proposal draws then y_dim simulator draws */
+    float zs[GLABC_MAX_BATCH][2 * GLABC_MAX_DIM];   /* storage for up to GLABC_MAX_BATCH proposals; larger batches: heap */
 } step_draws;
+
+/* zeroed draws with room for n_prop proposals; draws_release frees what draws_init took from the heap */
+static int draws_init(step_draws* s, int n_prop)
+{
+    memset(s, 0, sizeof *s);
+    s->z = s->zs;
+    if (n_prop > GLABC_MAX_BATCH) {
+        s->z = calloc((size_t)n_prop, sizeof s->zs[0]);
+        if (!s->z) return GLABC_ERR_ARG;
+    }
+    return 0;
+}
+
+static void draws_release(step_draws* s)
+{
+    if (s->z != s->zs) free(s->z);
+}
 
 /* Philox slots of one (chain, step): slot 0 = {branch, accept, resample hi, resample lo};
  * proposal j uses slots 1 + j*spp .. , spp = ceil((dp + y_dim)/4) blocks, dp = d rounded up to even:
@@ -521,8 +539,19 @@ static float isir_weight_of_state(const glabc_model* m, const glabc_dist* imp, c
 static int isir_move(const glabc_model* m, const glabc_dist* imp, int N, chain_state* s, const step_draws* dr)
 {
     int d = m->theta_dim, yd = m->y_dim;
-    float th[GLABC_MAX_BATCH + 1][GLABC_MAX_DIM], y[GLABC_MAX_BATCH + 1][GLABC_MAX_DIM];
-    float lw[GLABC_MAX_BATCH + 1], w[GLABC_MAX_BATCH + 1];
+    float th_s[GLABC_MAX_BATCH + 1][GLABC_MAX_DIM], y_s[GLABC_MAX_BATCH + 1][GLABC_MAX_DIM];
+    float lw_s[GLABC_MAX_BATCH + 1], w_s[GLABC_MAX_BATCH + 1];
+    float (*th)[GLABC_MAX_DIM] = th_s, (*y)[GLABC_MAX_DIM] = y_s, *lw = lw_s, *w = w_s;
+    void* heap = NULL;
+    if (N > GLABC_MAX_BATCH) {                      /* batches beyond the small arrays: one heap block */
+        const size_t rows = (size_t)N + 1;
+        heap = malloc(rows * (2 * sizeof th_s[0] + 2 * sizeof(float)));
+        if (!heap) return 0;
+        th = heap;
+        y = th + rows;
+        lw = (float*)(y + rows);
+        w = lw + rows;
+    }
     if (s->flags & GLABC_FLAG_LOCAL) s->log_w = isir_weight_of_state(m, imp, s);    /* :60-64 */
     s->flags &= ~GLABC_FLAG_LOCAL;                                                  /* :65 */
     memcpy(th[0], s->theta, sizeof(float) * d);
@@ -557,9 +586,9 @@ static int isir_move(const glabc_model* m, const glabc_dist* imp, int N, chain_s
         memcpy(s->theta, th[ind], sizeof(float) * d);
         memcpy(s->y, y[ind], sizeof(float) * yd);
         s->log_w = lw[ind];
-        return 1;
     }
-    return 0;
+    free(heap);
+    return ind > 0;
 }
 
 ORACLE_API int oracle_init_weights(const glabc_model* m, const glabc_dist* imp, const glabc_chains* c)
@@ -584,13 +613,14 @@ ORACLE_API int oracle_glmcmc_steps(const glabc_model* m, const glabc_dist* local
     if (rc) return rc;
     if (!c->log_w || !c->flags) return GLABC_ERR_NULL;
     int N = run->batch_size;
-    if (N < 1 || N > GLABC_MAX_BATCH) return GLABC_ERR_ARG;
+    if (N < 1 || N > GLABC_MAX_BATCH_WIDE) return GLABC_ERR_ARG;
+    if (N > GLABC_MAX_BATCH && run->tape) return GLABC_ERR_ARG;
     int d = m->theta_dim, yd = m->y_dim;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < c->n_chains; ++i) {
         chain_state s;
         step_draws dr;
-        memset(&dr, 0, sizeof dr);
+        if (draws_init(&dr, N)) continue;
         load_chain(&s, c, i, d, yd);
         for (int64_t t = 0; t < run->n_steps; ++t) {
             float prev[GLABC_MAX_DIM];
@@ -617,6 +647,7 @@ ORACLE_API int oracle_glmcmc_steps(const glabc_model* m, const glabc_dist* local
             record(run, c, i, t, d, s.theta, prev);                                 /* :89,104 */
         }
         store_chain(&s, c, i, d, yd);
+        draws_release(&dr);
     }
     return 0;
 }
@@ -654,7 +685,7 @@ ORACLE_API int oracle_globalmcmc_steps(const glabc_model* m, const glabc_dist* l
     for (int64_t i = 0; i < c->n_chains; ++i) {
         chain_state s;
         step_draws dr;
-        memset(&dr, 0, sizeof dr);
+        draws_init(&dr, GLABC_MAX_BATCH);
         load_chain(&s, c, i, d, yd);
         for (int64_t t = 0; t < run->n_steps; ++t) {
             float prev[GLABC_MAX_DIM];
@@ -1018,7 +1049,7 @@ ORACLE_API int oracle_glmala_steps(const glabc_model* m, const glabc_dist* imp, 
     for (int64_t i = 0; i < c->n_chains; ++i) {
         mala_state s;
         step_draws dr;
-        memset(&dr, 0, sizeof dr);
+        draws_init(&dr, GLABC_MAX_BATCH);
         for (int j = 0; j < d; ++j) {
             s.theta[j] = c->theta64[j * c->stride + i];
             s.grad[j] = c->grad[j * c->stride + i];
@@ -1365,7 +1396,7 @@ ORACLE_API int oracle_glmcmc_nf_step(const glabc_model* m, const glabc_dist* loc
     for (int64_t i = 0; i < C; ++i) {
         chain_state s;
         step_draws dr;
-        memset(&dr, 0, sizeof dr);
+        draws_init(&dr, GLABC_MAX_BATCH);
         load_chain(&s, c, i, d, yd);
         draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0, 1, d, yd, 0);
         int kk = pool->kk[i], moved = 0;
@@ -1529,13 +1560,14 @@ ORACLE_API void oracle_step_draws(uint64_t seed, uint64_t chain, uint32_t step, 
                                   float* u2, double* r, float* z)
 {
     step_draws dr;
-    memset(&dr, 0, sizeof dr);
+    if (draws_init(&dr, n_prop)) return;
     draws_from_philox(&dr, seed, chain, step, n_prop, d, yd, 0);
     u2[0] = dr.u_branch;
     u2[1] = dr.u_accept;
     *r = dr.u_resample;
     for (int j = 0; j < n_prop; ++j)
         for (int i = 0; i < d + yd; ++i) z[j * (d + yd) + i] = dr.z[j][i];
+    draws_release(&dr);
 }
 
 /* ========================================================================= */

@@ -304,6 +304,11 @@ SAMPLER_FIXTURES = {
                                         theta0_sd=1.0, local=G2(0.35), **{"global": ("gauss", [0.5, -0.25], [1.5, 0.75])}), "philox"),
     "glmcmc_philox_n16": ("glmcmc", dict(epsilon=0.3, gf=0.9, N=16, C=12, T=300, seed=5,
                                          theta0_sd=1.0, local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    # batches beyond the register kernels: 8 / 16 lanes of a wavefront share a chain (glabc_wide.hip); torch.sum's 8-wide path
+    "glmcmc_philox_n32": ("glmcmc", dict(epsilon=0.3, gf=0.8, N=32, C=8, T=250, seed=7, theta0_sd=1.0,
+                                         local=G2(0.35), **{"global": G2(1.0)}), "philox"),
+    "glmcmc_philox_n100": ("glmcmc", dict(epsilon=0.1, gf=0.7, N=100, C=6, T=150, seed=8, theta0_sd=1.0, chain0=123456789012,
+                                          local=G2(0.35), **{"global": ("gauss", [0.3, -0.2], [1.4, 1.1])}), "philox"),
     "glmcmc_philox_uniform": ("glmcmc", dict(epsilon=0.3, gf=0.7, N=4, C=16, T=500, seed=6, theta0_sd=1.0,
                                              local=("uniform", [-0.5, -0.5], [0.5, 0.5]),
                                              **{"global": ("uniform", [-3.0, -3.0], [3.0, 3.0])}), "philox"),

@@ -58,6 +58,7 @@ def descriptors(cfg, consts=None):
 
 SAMPLER_GOLDENS = [
     "glmcmc_philox_bench", "glmcmc_philox_n8", "glmcmc_philox_n1", "glmcmc_philox_n3", "glmcmc_philox_n16",
+    "glmcmc_philox_n32", "glmcmc_philox_n100",
     "glmcmc_philox_uniform", "globalmcmc_philox_bench", "globalmcmc_philox_wide",
     "glmcmc_tape_small", "globalmcmc_tape_small",
     "glmcmc_philox_gk", "glmcmc_philox_gk_gauss", "globalmcmc_philox_gk",

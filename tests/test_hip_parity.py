@@ -837,3 +837,81 @@ def test_glmala_law_matches_a_large_reference_sample(hip):
     for k in ("mean_abs_0", "mean_abs_1", "mean_sq_0", "mean_sq_1"):
         m, r, comb = report[k]
         assert comb / abs(r) < 2e-3 and abs(m - r) / abs(r) < 5e-3, (k, report[k])
+
+
+# ---------------------------------------------------------------------------------- wide batches (glabc_wide.hip)
+WIDE_CASES = [
+    # d, N, lanes (0 = library's choice), gf, eps, global spec, chains, T, debug_flags
+    (2, 17, 0, 0.9, 0.3, ("gauss", [0, 0], [1, 1]), 777, 60, 0),
+    (2, 32, 8, 0.8, 0.05, ("gauss", [0, 0], [1, 1]), 1000, 80, 0),
+    (2, 32, 16, 0.8, 0.05, ("gauss", [0, 0], [1, 1]), 1000, 80, 0),
+    (2, 32, 32, 0.8, 0.05, ("gauss", [0, 0], [1, 1]), 333, 50, 0),
+    (2, 32, 64, 0.8, 0.05, ("gauss", [0, 0], [1, 1]), 130, 50, 0),
+    (2, 64, 0, 0.5, 0.3, ("uniform", [-3, -3], [3, 3]), 500, 60, 0),
+    (2, 100, 0, 0.7, 0.1, ("gauss", [0.3, -0.2], [1.4, 1.1]), 300, 50, 0),
+    (2, 256, 0, 0.9, 0.3, ("gauss", [0, 0], [1, 1]), 200, 30, 0),
+    (2, 256, 64, 0.9, 0.3, ("gauss", [0, 0], [1, 1]), 100, 30, 1),          # GLABC_DEBUG_EXACT_INDEX: the reference's loop always
+    (2, 1000, 0, 0.9, 0.3, ("gauss", [0, 0], [1, 1]), 64, 20, 0),           # torch.sum's cascade levels (n >= 512)
+    (1, 40, 0, 0.6, 0.3, ("uniform", [-3], [3]), 400, 60, 0),
+    (3, 33, 0, 0.6, 0.4, ("gauss", [0, 0, 0], [1.2, 1.2, 1.2]), 300, 50, 0),
+    (4, 20, 0, 0.6, 0.5, ("gauss", [0] * 4, [1.2] * 4), 300, 50, 0),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "d%d-N%d-L%d-%s%s" % (c[0], c[1], c[2], c[5][0], "-exact" if c[8] else ""))
+def test_wide_batches_equal_oracle(hip, oracle, case):
+    """batch_size > 16: lane groups of a wavefront share a chain's proposals (ATen-order total over 32 accumulator lanes,
+    chunked double prefix sums for the index).  Histories, final state, flags, log-weights, move counts and the streamed
+    sums equal the CPU checker's bit for bit, for every group width."""
+    from test_stream_independence import abs_gauss_model
+    d, N, lanes, gf, eps, gspec, n, T, dbg = case
+    model = abs_gauss_model(d, eps)
+    local = make_dist(("gauss", [0.0] * d, [0.35] * d)).descriptor()
+    glob = make_dist(gspec).descriptor()
+    rng = np.random.default_rng(N * 7 + d)
+    theta0 = rng.standard_normal((n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    hist, chains, mom = hip_run("glmcmc", model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True,
+                                lanes=lanes, debug_flags=dbg, steps_per_launch=23)
+    hh, hc, hm = oracle_run(oracle, "glmcmc", model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True)
+    same = bits(hist) == bits(hh)
+    assert same.all(), "first mismatch at (t, dim, chain) = %s" % (np.argwhere(~same)[0],)
+    assert_same_state(chains, hc, True)
+    assert hc.n_moves.sum() > n
+    assert np.array_equal(mom.sum_theta.cpu().numpy(), hm.sum_theta)
+    assert np.array_equal(mom.sum_outer.cpu().numpy(), hm.sum_outer)
+    assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
+
+
+def test_wide_batch_gk_model_equals_oracle(hip, oracle):
+    from glabcmcmc_amd.examples.GK import GK_set
+    cfg = dict(model="gk", epsilon=1.0, local=("gauss", [0.0] * 4, [0.15] * 4), **{"global": ("uniform", [0.0] * 4, [10.0] * 4)})
+    model, local, glob = descriptors(cfg)
+    rng = np.random.default_rng(5)
+    n, T, N = 300, 40, 48
+    theta0 = rng.uniform(0.5, 5.0, (n, 4)).astype(np.float32)
+    torch.manual_seed(3)
+    y0 = GK_set(1.0).generate_samples(torch.from_numpy(theta0)).numpy().copy()
+    hist, chains, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, 77, 0.8, N, chain0=5)
+    hh, hc, _ = oracle_run(oracle, "glmcmc", model, local, glob, theta0, y0, T, 77, 0.8, N, chain0=5)
+    assert np.array_equal(bits(hist), bits(hh))
+    assert_same_state(chains, hc, True)
+    assert hc.n_moves.sum() > n
+
+
+def test_wide_batch_through_the_python_api_equals_the_generic_path(hip):
+    """GLMCMC(..., batch_size=40): the fused wide kernel and the split-phase path (propose / Mixture_set's row-wise
+    kernels / select) are two implementations of the same specification -- identical chains."""
+    from glabcmcmc_amd import GLMCMC, distribution
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    m = Mixture_set(0.2)
+    lp = distribution.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35])))
+    ip = distribution.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0]))
+    g = torch.Generator().manual_seed(5)
+    th0 = torch.randn(512, 2, generator=g)
+    y0 = th0.abs() + 0.2236 * torch.randn(512, 2, generator=g)
+    a = GLMCMC(m, 60, th0, y0, lp, None, 0.8, ip, 40, seed=3, verbose=False, path="fused")
+    b = GLMCMC(m, 60, th0, y0, lp, None, 0.8, ip, 40, seed=3, verbose=False, path="generic")
+    assert np.array_equal(bits(a.numpy()), bits(b.numpy()))
+    assert (a[1:] != a[:-1]).any()
