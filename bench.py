@@ -328,6 +328,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true", help="diagnostic: do not write Theta_Re rows")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default; geometry only)")
+    ap.add_argument("--batch", type=int, default=NBATCH, help="iSIR batch size N (default 5 = BASELINE configs[1]); above 16 the "
+                    "wide kernel of glabc_wide.hip runs")
     ap.add_argument("--couplings", type=int, default=8, help="nf workload: number of couplings")
     ap.add_argument("--no-sentinel", action="store_true", help="callback workload: skip the GLMCMC.py:92-93 redraw check "
                     "(one device->host sync per iteration)")
@@ -403,7 +405,7 @@ def main():
                                     moments=mom, steps_per_launch=K)
         else:
             entry = "glabc_globalmcmc_steps" if args.workload == "globalmcmc" else "glabc_glmcmc_steps"
-            engine.run_steps(entry, model, lp, ip, chains, K, 1 + step_idx[0] * K, seed, gf, NBATCH,
+            engine.run_steps(entry, model, lp, ip, chains, K, 1 + step_idx[0] * K, seed, gf, args.batch,
                              history=hist, moments=mom, steps_per_launch=K, lanes_per_chain=args.lanes)
         step_idx[0] += 1
 
@@ -485,13 +487,15 @@ def main():
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"glmcmc": "GLMCMC iSIR N=5 gf=0.9, Mixture_set eps=0.05 d=2 (BASELINE configs[1])",
+            "config": {"workload": {"glmcmc": "GLMCMC iSIR N=%d gf=0.9, Mixture_set eps=0.05 d=2%s"
+                                              % (args.batch, " (BASELINE configs[1])" if args.batch == NBATCH else ""),
                                     "globalmcmc": "GlobalMCMC gf=0.5, Mixture_set eps=0.05 d=2 (BASELINE configs[0], batched)",
                                     "glmala": "GLMALA iSIR N=5 gf=0.8 tau=0.3 num_grad=100, Mixture_set eps=0.05 d=2 "
                                               "(BASELINE configs[2])",
                                     "gk": "GLMCMC iSIR N=5 gf=0.9 on the g-and-k model (theta_dim 4, y_dim 8, eps 0.6), "
                                           "chains sharded over the GPUs (BASELINE configs[3])"}[args.workload],
-                       "chains_per_gpu": n, "iters_per_step": K, "batch_size": NBATCH, "history": not args.no_history,
+                       "chains_per_gpu": n, "iters_per_step": K, "batch_size": args.batch if args.workload in ("glmcmc", "gk") else NBATCH,
+                       "history": not args.no_history,
                        "lanes_per_chain": args.lanes or "auto",
                        "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "esjd_mean": float(esjd_all[ok].double().mean()), "esjd_nan_frac": float(1.0 - ok.double().mean()),
@@ -500,7 +504,8 @@ def main():
             "moment_iters": steps_all,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {"glmcmc": "glabc::sampler_kernel<GLMCMC, D=2, N=5>",
+                         "kernel": {"glmcmc": "glabc::sampler_kernel<GLMCMC, D=2, N=%d>" % args.batch if args.batch <= 16
+                                    else "glabc::wide_kernel<D=2, L> N=%d" % args.batch,
                                     "globalmcmc": "glabc::sampler_kernel<GLOBAL, D=2, N=1>",
                                     "glmala": "glabc::glmala_kernel<D=2, N=5>",
                                     "gk": "glabc::sampler_kernel<GLMCMC, D=4, YD=8, N=5>"}[args.workload], "kernel_ms": kernel_ms,

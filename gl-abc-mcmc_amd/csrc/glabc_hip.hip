@@ -427,22 +427,51 @@ struct GammaArgs {
     int64_t n;
 };
 
+// one coordinate's log(pdf), distribution.py:133-136
+__device__ __forceinline__ double gamma_log_pdf(const glabc_gamma& g, int j, double z)
+{
+    const double x = z / g.scale[j];
+    if (x >= 0.0) {                                        // scipy's support of gamma is closed at 0
+        const double am1 = g.shape[j] - 1.0;
+        const double xl = am1 == 0.0 ? 0.0 : am1 * glabc_log(x);                       // scipy.special.xlogy
+        const double p = glabc_exp((xl - x) - g.gammaln[j]) / g.scale[j];               // gamma.pdf
+        return p > 0.0 ? glabc_log(p) : -__builtin_inf();                               // distribution.py:136
+    }
+    return -__builtin_inf();
+}
+
+struct GammaFwdArgs {
+    glabc_gamma g;
+    double* z;
+    double* log_p;
+    int64_t n, row0;
+    uint32_t seed_lo, seed_hi;
+};
+
+// Gamma.forward, distribution.py:106-121: one work-item per row
+__global__ void __launch_bounds__(256) gamma_forward_kernel(const GammaFwdArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const uint64_t gid = (uint64_t)(a.row0 + i);
+    double acc = 0.0;
+    for (int j = 0; j < a.g.dim; ++j) {
+        const double z = glabc_gamma_draw(a.g.shape[j], (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)j, a.seed_lo, a.seed_hi) *
+                         a.g.scale[j];
+        a.z[i * a.g.dim + j] = z;
+        const double lp = gamma_log_pdf(a.g, j, z);
+        acc = j == 0 ? lp : acc + lp;
+    }
+    a.log_p[i] = acc;
+}
+
 __global__ void __launch_bounds__(256) gamma_log_prob_kernel(const GammaArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
     double acc = 0.0;
     for (int j = 0; j < a.g.dim; ++j) {
-        const double x = a.z[i * a.g.dim + j] / a.g.scale[j];
-        double lp;
-        if (x >= 0.0) {                                    // scipy's support of gamma is closed at 0
-            const double am1 = a.g.shape[j] - 1.0;
-            const double xl = am1 == 0.0 ? 0.0 : am1 * glabc_log(x);               // scipy.special.xlogy
-            const double p = glabc_exp((xl - x) - a.g.gammaln[j]) / a.g.scale[j];     // gamma.pdf
-            lp = p > 0.0 ? glabc_log(p) : -__builtin_inf();                         // distribution.py:136
-        } else {
-            lp = -__builtin_inf();
-        }
+        const double lp = gamma_log_pdf(a.g, j, a.z[i * a.g.dim + j]);
         acc = j == 0 ? lp : acc + lp;                                               // torch.sum(dim=1), distribution.py:137
     }
     a.out[i] = acc;
@@ -958,6 +987,28 @@ extern "C" __attribute__((visibility("default"))) int glabc_gamma_log_prob(const
     a.out = out;
     a.n = n;
     hipLaunchKernelGGL(gamma_log_prob_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return finish_launch();
+}
+
+extern "C" __attribute__((visibility("default"))) int glabc_gamma_forward(const glabc_gamma* dist, int64_t n, uint64_t seed,
+                                                                          int64_t row0, double* z_out, double* log_p_out, void* stream)
+{
+    if (!dist || !z_out || !log_p_out) return GLABC_ERR_NULL;
+    if (dist->dim < 1 || dist->dim > 3) return GLABC_ERR_DIM;
+    if (n < 0 || row0 < 0) return GLABC_ERR_ARG;
+    for (int j = 0; j < dist->dim; ++j)
+        if (!(dist->shape[j] > 0.0) || !std::isfinite(dist->shape[j]) || !(dist->scale[j] > 0.0) || !std::isfinite(dist->gammaln[j]))
+            return GLABC_ERR_ARG;
+    if (n == 0) return GLABC_OK;
+    GammaFwdArgs a;
+    a.g = *dist;
+    a.z = z_out;
+    a.log_p = log_p_out;
+    a.n = n;
+    a.row0 = row0;
+    a.seed_lo = (uint32_t)seed;
+    a.seed_hi = (uint32_t)(seed >> 32);
+    hipLaunchKernelGGL(gamma_forward_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return finish_launch();
 }
 

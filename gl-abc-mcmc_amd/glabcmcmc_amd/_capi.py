@@ -244,6 +244,7 @@ ENTRY_POINTS = {
     "glabc_dist_log_prob": (C.c_int, [_P(Dist), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_dist_forward": (C.c_int, [_P(Dist), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "glabc_gamma_log_prob": (C.c_int, [_P(GammaDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_gamma_forward": (C.c_int, [_P(GammaDesc), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "glabc_model_prior_log_prob": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_discrepancy": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_model_log_kernel": (C.c_int, [_P(Model), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

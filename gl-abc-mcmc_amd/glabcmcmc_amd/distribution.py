@@ -126,12 +126,35 @@ class Uniform(BaseDistribution):
 class Gamma(BaseDistribution):
     """Multivariate independent Gamma distribution (distribution.py:90-137); float64, SciPy."""
 
-    def __init__(self, Shape, Rate):
+    def __init__(self, Shape, Rate, device=None, seed=None):
         super().__init__()
         self.Shape = Shape.numpy()
         self.Rate = Rate.numpy()
+        # device / seed are additions: with a CUDA device forward() draws on the GPU (glabc_gamma_forward: Marsaglia-Tsang
+        # in double on the Philox stream of `seed`, a fresh block of rows per call); without, the reference's SciPy draw
+        self.device = None if device is None else torch.device(device)
+        self.seed = seed
+        self._rows_drawn = 0
 
-    def forward(self, num_samples=1, context=None):
+    def forward(self, num_samples=1, context=None, device=None, seed=None, row0=None):
+        dev = self.device if device is None else torch.device(device)
+        if dev is not None and dev.type == "cuda":
+            desc = self.descriptor()
+            if seed is None:
+                if self.seed is None:
+                    self.seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+                seed = self.seed
+            if row0 is None:
+                row0 = self._rows_drawn
+                self._rows_drawn += int(num_samples)
+            z = torch.empty(num_samples, desc.dim, dtype=torch.float64, device=dev)
+            log_p = torch.empty(num_samples, dtype=torch.float64, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            with torch.cuda.device(dev):
+                _capi.check(_capi.lib().glabc_gamma_forward(C.byref(desc), int(num_samples), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                            int(row0), z.data_ptr(), log_p.data_ptr(), C.c_void_p(stream)),
+                            "Gamma.forward")
+            return z.view((num_samples,) + tuple(self.Shape.shape)), log_p
         from scipy.stats import gamma
         size = (num_samples,) + tuple(self.Shape.shape)
         z = torch.tensor(gamma.rvs(self.Shape, scale=1 / self.Rate, size=size))

@@ -122,12 +122,18 @@ class ProposalCallbacks:
     def _dev(self, t, rows):
         return torch.as_tensor(t).detach().to(device=self.device, dtype=torch.float32).reshape(rows, -1).contiguous()
 
+    def _draw(self, n):
+        try:
+            return self.dist.forward(n, device=self.device)        # the build's Gamma draws on the device (glabc_gamma_forward)
+        except TypeError:
+            return self.dist.forward(n)                            # anyone else's distribution: its own generator
+
     def forward(self, n):
-        z, lp = self.dist.forward(n)
+        z, lp = self._draw(n)
         return self._dev(z, n), self._dev(lp, n).view(-1)
 
     def sample(self, n):
-        return self._dev(self.dist.sample(n), n)
+        return self._dev(self._draw(n)[0], n)
 
     def log_prob(self, theta):
         try:

@@ -381,6 +381,12 @@ typedef struct glabc_gamma {
 
 int glabc_gamma_log_prob(const glabc_gamma* dist, const double* z, int64_t n, double* out, void* stream);
 
+/* Gamma.forward(n), distribution.py:106-121, drawn on the device: z[r][j] = glabc_gamma_draw(shape_j; Philox(seed; row0 + r,
+ * j, attempt)) * scale_j (include/glabc_numerics.h: Marsaglia-Tsang in double; the reference draws scipy.stats.gamma.rvs from
+ * NumPy's generator) and log_p[r] = Gamma.log_prob(z[r]).  z_out[n][dim] row-major float64, log_p_out[n] float64. */
+int glabc_gamma_forward(const glabc_gamma* dist, int64_t n, uint64_t seed, int64_t row0, double* z_out, double* log_p_out,
+                        void* stream);
+
 /* Model callbacks on n row-major points (Mixture.py:28-45): used by the host
  * mirror's Model class and by the parity tests. */
 int glabc_model_prior_log_prob(const glabc_model* model, const float* theta, int64_t n, float* out, void* stream);

@@ -298,6 +298,44 @@ GLABC_HD double glabc_exp(double x)
     return (y * s1) * s2;
 }
 
+/* ---- Gamma(shape, 1) variate in double (distribution.py:106-121 draws scipy.stats.gamma.rvs from NumPy's generator) ------
+ * Marsaglia & Tsang (2000): d = a - 1/3, c = 1/sqrt(9 d); x ~ N(0,1), v = (1 + c x)^3 > 0, accept if
+ * u < 1 - 0.0331 x^4 or log u < x^2/2 + d (1 - v + log v); result d v.  For shape < 1: Gamma(shape + 1) U^(1/shape).
+ * The normal comes from Marsaglia's polar method (log, sqrt and division only -- no trigonometric function to specify in
+ * double).  One Philox block per attempt, counter (c0, c1, c2, attempt): words 0, 1 -> the point in the square, words 2, 3
+ * -> the 53-bit accept uniform; attempt 0xffffffff feeds the shape < 1 boost.  Acceptance is > 75 % per attempt; after 256
+ * rejected attempts (probability < 1e-150) the mode-like value d is returned so that every lane terminates.
+ * Plain IEEE double operations: host and device agree bit for bit under -ffp-contract=off. */
+GLABC_HD double glabc_gamma_draw(double shape, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1)
+{
+    const double a = shape < 1.0 ? shape + 1.0 : shape;
+    const double d = a - 1.0 / 3.0;
+    const double c = 1.0 / __builtin_sqrt(9.0 * d);
+    double g = d;
+    for (uint32_t t = 0; t < 256u; ++t) {
+        const glabc_u32x4 w = glabc_philox4x32_10(c0, c1, c2, t, k0, k1);
+        const double u1 = ((double)w.v[0] + 0.5) * 0x1p-31 - 1.0, u2 = ((double)w.v[1] + 0.5) * 0x1p-31 - 1.0;
+        const double s = u1 * u1 + u2 * u2;
+        if (!(s < 1.0) || s == 0.0) continue;
+        const double x = u1 * __builtin_sqrt(-2.0 * glabc_log(s) / s);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        const double u = glabc_uniform_f64(w.v[2], w.v[3]);
+        const double x2 = x * x;
+        if (u < 1.0 - 0.0331 * (x2 * x2) || glabc_log(u) < 0.5 * x2 + d * ((1.0 - v) + glabc_log(v))) {
+            g = d * v;
+            break;
+        }
+    }
+    if (shape < 1.0) {
+        const glabc_u32x4 w = glabc_philox4x32_10(c0, c1, c2, 0xffffffffu, k0, k1);
+        const double u = (((double)(w.v[0] >> 5) * 67108864.0 + (double)(w.v[1] >> 6)) + 0.5) * 0x1p-53;       /* in (0, 1) */
+        g = g * glabc_exp(glabc_log(u) / shape);
+    }
+    return g;
+}
+
 /* ---- exact, order-independent sums for GLMALA's gradient statistics (GLMALA.py:86-89) ------------------------
  * The mean and variance of the num_grad simulated discrepancies are accumulated on data shifted by a centre c
  * in FIXED POINT: d = x - c is an exact double (x, c are float32 values), q = rint(d * 2^40) is an exact integer for

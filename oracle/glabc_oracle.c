@@ -202,6 +202,20 @@ ORACLE_API int oracle_gamma_log_prob(const glabc_gamma* g, const double* z, int6
     return 0;
 }
 
+/* Gamma.forward, distribution.py:106-121, with the device entry point's draws (include/glabc.h, glabc_gamma_forward) */
+ORACLE_API int oracle_gamma_forward(const glabc_gamma* g, int64_t n, uint64_t seed, int64_t row0, double* z, double* log_p)
+{
+    if (!g || !z || !log_p) return GLABC_ERR_NULL;
+    if (g->dim < 1 || g->dim > 3) return GLABC_ERR_DIM;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t gid = (uint64_t)(row0 + i);
+        for (int j = 0; j < g->dim; ++j)
+            z[i * g->dim + j] = glabc_gamma_draw(g->shape[j], (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)j, (uint32_t)seed,
+                                                 (uint32_t)(seed >> 32)) * g->scale[j];       /* gamma.rvs(shape, scale=1/rate), :118 */
+    }
+    return oracle_gamma_log_prob(g, z, n, log_p);                                               /* :120 */
+}
+
 /* forward() with the noise supplied by the caller: noise[n][dim] -> z[n][dim], log_p[n]. */
 ORACLE_API int oracle_dist_forward(const glabc_dist* dist, const float* noise, int64_t n, float* z, float* log_p)
 {

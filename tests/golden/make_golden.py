@@ -503,6 +503,29 @@ def primitives():
         out["resample_%d_idx" % i] = idx.numpy().astype(np.int64)
         cases.append((i, P, N, kind, int(idx.numel())))
     out["resample_cases"] = np.array(repr(cases))
+    # Gamma.forward (distribution.py:106-121): the reference draws scipy.stats.gamma.rvs from NumPy's generator; here rvs is
+    # replaced by the build's specified draw (include/glabc_numerics.h glabc_gamma_draw, through the CPU checker) so that
+    # the reference's forward() returns (z, log_prob(z)) for exactly the variates the device kernel makes
+    import ctypes
+    import scipy.stats
+    from glabcmcmc_amd import distribution as bdist
+    L = oracle_lib.load()
+    for tag, shape, rate, seed, row0 in (("a", [2.0, 3.0], [1.0, 2.0], 11, 0), ("b", [0.5], [3.0], 12, 10 ** 12),
+                                         ("c", [1.0, 7.5, 0.3], [0.5, 1.5, 4.0], 13, 77)):
+        g = rdist.Gamma(torch.tensor(shape), torch.tensor(rate))
+        desc = bdist.Gamma(torch.tensor(shape), torch.tensor(rate)).descriptor()
+        n, k = 400, len(shape)
+        zz, lp = np.empty((n, k)), np.empty(n)
+        assert L.oracle_gamma_forward(ctypes.byref(desc), n, seed, row0, zz.ctypes.data, lp.ctypes.data) == 0
+        saved = scipy.stats.gamma.rvs
+        rdist.gamma.rvs = lambda a, scale=1, size=None, zz=zz: zz.copy()
+        try:
+            z_ref, lp_ref = g.forward(n)
+        finally:
+            rdist.gamma.rvs = saved
+        out["gf_%s_shape" % tag], out["gf_%s_rate" % tag] = np.array(shape, np.float32), np.array(rate, np.float32)
+        out["gf_%s_seed_row0" % tag] = np.array([seed, row0], np.int64)
+        out["gf_%s_z" % tag], out["gf_%s_log_p" % tag] = z_ref.numpy(), lp_ref.numpy()
     np.savez_compressed(os.path.join(HERE, "primitives.npz"), **out)
     print("primitives: %d arrays" % len(out))
 

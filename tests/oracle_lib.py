@@ -49,6 +49,7 @@ _SIG = {
     "oracle_kde_train_weights": (C.c_int, [_P(A.Model), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "oracle_dist_forward_philox": (C.c_int, [_P(A.Dist), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
     "oracle_gamma_log_prob": (C.c_int, [_P(A.GammaDesc), C.c_void_p, C.c_int64, C.c_void_p]),
+    "oracle_gamma_forward": (C.c_int, [_P(A.GammaDesc), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
     "oracle_esjd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "oracle_philox4x32_10": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "oracle_expf_v": (None, [C.c_void_p, C.c_int64, C.c_void_p]),

@@ -270,3 +270,20 @@ def test_gamma_log_prob(oracle, prim, tag):
     assert np.max(np.abs(out[fin] - ref[fin]) / np.maximum(1, np.abs(ref[fin]))) < 1e-6
     # host mirror on CPU tensors = the reference's own SciPy path
     assert np.array_equal(g.log_prob(torch.from_numpy(z)).numpy(), ref)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gamma_forward(oracle, prim, tag):
+    """Gamma.forward (distribution.py:106-121): the specified Philox / Marsaglia-Tsang draw is stable (same variates as when
+    the fixture was made) and the log_p it returns equals the REFERENCE's forward() on those variates (scipy's pdf, float64)."""
+    import torch
+    from glabcmcmc_amd import distribution
+    g = distribution.Gamma(torch.from_numpy(prim["gf_%s_shape" % tag]), torch.from_numpy(prim["gf_%s_rate" % tag]))
+    d = g.descriptor()
+    seed, row0 = (int(v) for v in prim["gf_%s_seed_row0" % tag])
+    z_ref, lp_ref = prim["gf_%s_z" % tag], prim["gf_%s_log_p" % tag]
+    z, lp = np.empty_like(z_ref), np.empty_like(lp_ref)
+    assert oracle.oracle_gamma_forward(C.byref(d), len(z), seed, row0, z.ctypes.data, lp.ctypes.data) == 0
+    assert np.array_equal(z.view(np.uint64), z_ref.view(np.uint64))
+    assert (z > 0).all() and np.isfinite(lp_ref).all()
+    assert np.max(np.abs(lp - lp_ref) / np.maximum(1, np.abs(lp_ref))) < 1e-12
