@@ -327,7 +327,10 @@ def main():
     ap.add_argument("--iters", type=int, default=2000, help="MH iterations fused into one launch (= one bench step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-history", action="store_true", help="diagnostic: do not write Theta_Re rows")
+    ap.add_argument("--no-moments", action="store_true", help="diagnostic: do not stream the ESJD / moment sums (the JSON line "
+                    "then carries no ESJD / moments)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default; geometry only)")
+    ap.add_argument("--debug-flags", type=int, default=0, help="glabc_run.debug_flags (execution strategy only; results unchanged)")
     ap.add_argument("--batch", type=int, default=NBATCH, help="iSIR batch size N (default 5 = BASELINE configs[1]); above 16 the "
                     "wide kernel of glabc_wide.hip runs")
     ap.add_argument("--couplings", type=int, default=8, help="nf workload: number of couplings")
@@ -406,7 +409,10 @@ def main():
         else:
             entry = "glabc_globalmcmc_steps" if args.workload == "globalmcmc" else "glabc_glmcmc_steps"
             engine.run_steps(entry, model, lp, ip, chains, K, 1 + step_idx[0] * K, seed, gf, args.batch,
-                             history=hist, moments=mom, steps_per_launch=K, lanes_per_chain=args.lanes)
+                             history=hist, moments=None if args.no_moments else mom, steps_per_launch=K,
+                             lanes_per_chain=args.lanes, debug_flags=args.debug_flags)
+            if args.no_moments:
+                mom.steps += K
         step_idx[0] += 1
 
     def barrier():

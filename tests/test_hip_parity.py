@@ -306,7 +306,8 @@ def test_bad_arguments_are_refused(hip):
         return hip.glabc_glmcmc_steps(C.byref(m), C.byref(lo), C.byref(g), C.byref(c), C.byref(run), None)
 
     assert call() == 0
-    assert call(batch_size=0) == -4 and call(batch_size=17) == -4 and call(n_steps=-1) == -4
+    assert call(batch_size=0) == -4 and call(batch_size=4097) == -4 and call(n_steps=-1) == -4
+    assert call(batch_size=17, lanes_per_chain=2) == -4 and call(batch_size=5, lanes_per_chain=8) == -4
     bad = make_dist(("gauss", [0, 0], [1, 1])).descriptor()
     bad.p2[0] = float("nan")
     assert call(g=bad) == -4
