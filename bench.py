@@ -458,14 +458,16 @@ def main():
         # read correction applied) for exactly this configuration: profiles/r01_f_pmc_summary.json
         traffic, valu = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_f_pmc_summary.json")) as f:
+            pmc_file = "r02_pmc_summary.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) \
+                else "r01_f_pmc_summary.json"
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
             if args.workload == "glmcmc" and pmc["config"] == {"chains": n, "iters_per_launch": K,
                                                                "history": not args.no_history}:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]["total"]
                 per_step = pmc["derived"]["valu_insts_per_wave_step"]
                 wave_insts_per_s = per_step * (n / 64.0) * K / (kernel_ms * 1e-3)      # live kernel time x counted instructions
-                valu = {"source": "profiles/r01_f_pmc_summary.json (rocprofv3 --pmc, round 1) + this run's kernel time",
+                valu = {"source": "profiles/%s (rocprofv3 --pmc) + this run's kernel time" % pmc_file,
                         "valu_insts_per_wave_step": per_step,
                         "valu_active_fraction": pmc["derived"]["valu_active_fraction"],
                         "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
@@ -486,6 +488,17 @@ def main():
                         "issue_frac": wave_insts_per_s / (1024 * 1.0e9),
                         "mix_saturated_wave_insts_per_s": 6.4e11,
                         "mix_frac": wave_insts_per_s / 6.4e11}
+            if args.workload == "glmala":                  # the counted instructions of glmala_kernel x this run's kernel time
+                with open(os.path.join(ROOT, "profiles", "r02_pmc_glmala.json")) as f:
+                    pg = json.load(f)
+                if pg["config"] == {"chains": n, "iters_per_launch": K}:
+                    per_step = pg["derived"]["valu_insts_per_wave_step"]
+                    wips = per_step * (n / 64.0) * K / (kernel_ms * 1e-3)
+                    valu = {"source": "profiles/r02_pmc_glmala.json (rocprofv3 --pmc) + this run's kernel time",
+                            "valu_insts_per_wave_step": per_step, "wave_insts_per_s": wips,
+                            "valu_active_fraction": pg["derived"].get("valu_active_fraction"),
+                            "cycles_per_valu_inst": pg["derived"].get("cycles_per_valu_inst"),
+                            "vector_peak_wave_insts_per_s": 1024 * 2.4e9 / 2, "frac_of_vector_peak": wips / (1024 * 2.4e9 / 2)}
         except (OSError, KeyError, ValueError):
             pass
         out = {
