@@ -2,7 +2,7 @@
 
     python tests/fuzz_parity.py [seconds] [seed]
 
-Random theta_dim, batch size, epsilon (1e-4 .. 10), global_frequency, Gaussian / Uniform proposals with random
+Random theta_dim, batch size (every fourth GLMCMC case beyond 16: the wide kernel, up to 1200 proposals), epsilon (1e-4 .. 10), global_frequency, Gaussian / Uniform proposals with random
 parameters, y_obs (also near zero), lanes per chain, iterations per launch, chain id offsets -- GLMCMC and GlobalMCMC
 histories, final states and streaming sums must agree with the oracle bit for bit; every fourth case is GLMALA
 (random tau, num_grad, float64 state, gradients), every eighth the g-and-k Model.
@@ -37,6 +37,9 @@ def one_case(rng, oracle, k):
     d = int(rng.integers(1, 5))
     algo = "glmcmc" if rng.random() < 0.7 else "globalmcmc"
     N = int(rng.integers(1, 17)) if algo == "glmcmc" else 1
+    wide = algo == "glmcmc" and rng.random() < 0.25                      # glabc_wide.hip: lane groups share a chain's proposals
+    if wide:
+        N = int(rng.choice([17, 31, 32, 33, 64, 65, int(rng.integers(17, 300)), int(rng.integers(300, 1200))]))
     eps = float(np.exp(rng.uniform(np.log(1e-4), np.log(10))))
     gf = float(rng.choice([0.0, 1.0, rng.random()]))
     lspec, gspec = random_dist(rng, d, True), random_dist(rng, d, False)
@@ -54,6 +57,9 @@ def one_case(rng, oracle, k):
     local, glob = make_dist(lspec).descriptor(), make_dist(gspec).descriptor()
     n, T = int(rng.integers(1, 700)), int(rng.integers(1, 60))
     lanes = int(rng.choice([0, 1, 2, 4])) if algo == "glmcmc" else 0
+    if wide:
+        n, T = int(rng.integers(1, 200 if N < 300 else 40)), int(rng.integers(1, 25))
+        lanes = int(rng.choice([0, 8, 16, 32, 64]))
     spl = int(rng.integers(1, T + 1))
     seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
     theta0 = rng.normal(0, 1, (n, d)).astype(np.float32)
