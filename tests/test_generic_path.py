@@ -447,3 +447,74 @@ def test_hip_rowsum_of_any_length_matches_torch_sum(hip):
         out = torch.empty(x.shape[0], dtype=torch.float32, device="cuda")
         assert hip.glabc_selftest_rowsum(x.data_ptr(), x.shape[0], n, out.data_ptr(), None) == 0
         assert np.array_equal(bits(out.cpu().numpy()), bits(p["rowsum_%d_sum" % n])), n
+
+
+class WideSummaryModel:
+    """theta_dim 12 > GLABC_MAX_DIM, y_dim 3 != theta_dim: sizes only the split-phase path with callback proposals handles"""
+
+    def __init__(self):
+        self.theta_dim, self.y_dim, self.epsilon = 12, 3, 0.5
+        self.y_obs = torch.tensor([[1.0, 0.5, 2.0]])
+
+    def generate_samples(self, theta, num_samples=1):
+        t = theta.reshape(-1, 12)
+        s = torch.stack([t[:, :4].abs().mean(1), t[:, 4:8].mean(1), (t[:, 8:] ** 2).mean(1)], dim=1)
+        return s + 0.1 * torch.randn_like(s)
+
+    def prior_log_prob(self, samples):
+        return -0.5 * (samples.reshape(-1, 12) ** 2).sum(1)
+
+    def discrepancy(self, y):
+        return ((y.reshape(-1, 3) - self.y_obs.to(y.device)) ** 2).sum(1).sqrt()
+
+    def calculate_log_kernel(self, y, epsilon=None):
+        e = self.discrepancy(y) / self.epsilon
+        return -0.5 * e * e
+
+
+@pytest.mark.gpu
+def test_hip_theta_dim_beyond_max_dim_and_other_y_dim(hip):
+    from glabcmcmc_amd import GLMCMC, GlobalMCMC
+    m = WideSummaryModel()
+    n = 2048
+    th0 = torch.randn(n, 12)
+    y0 = m.generate_samples(th0)
+    lp, ip = MyProposal(12, 0.15), MyProposal(12, 1.0)
+    torch.manual_seed(0)
+    out = GLMCMC(m, 80, th0, y0, lp, None, 0.5, ip, 7, seed=1, verbose=False, return_device=True)
+    assert out.shape == (80, n, 12) and torch.isfinite(out).all()
+    d_first = m.discrepancy(m.generate_samples(out[1])).mean().item()
+    d_last = m.discrepancy(m.generate_samples(out[-1])).mean().item()
+    assert d_last < 0.7 * d_first                                     # the chains move toward the observation
+    out2 = GlobalMCMC(m, 40, th0, y0, ip, None, 0.3, lp, seed=2, verbose=False, return_device=True)
+    assert out2.shape == (40, n, 12) and (out2[1:] != out2[:-1]).any()
+
+
+@pytest.mark.gpu
+def test_hip_split_phase_entry_points_validate(hip):
+    """NULL pointers, bad sizes, zero chains: status codes, no launch"""
+    from glabcmcmc_amd import engine
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.zeros(4, 2), torch.zeros(4, 2), dev)
+    cs = chains.struct()
+    run = A.Run()
+    run.seed, run.step0, run.n_steps, run.global_frequency, run.batch_size = 1, 1, 1, 0.5, 3
+    io = A.StepIO()
+    io.n_prop, io.theta_dim, io.y_dim = 3, 2, 2
+    g = make_dist(("gauss", [0, 0], [1, 1])).descriptor()
+    assert hip.glabc_propose(A.ALGO_GLMCMC, C.byref(g), C.byref(g), C.byref(cs), C.byref(run), C.byref(io), None) == -1   # NULL buffers
+    assert hip.glabc_select(A.ALGO_GLMCMC, C.byref(g), C.byref(cs), C.byref(run), C.byref(io), None) == -1
+    assert hip.glabc_propose(7, C.byref(g), C.byref(g), C.byref(cs), C.byref(run), C.byref(io), None) == -3                 # unknown algo
+    run.n_steps = 2
+    assert hip.glabc_propose(A.ALGO_GLMCMC, C.byref(g), C.byref(g), C.byref(cs), C.byref(run), C.byref(io), None) == -4     # one iteration per call
+    run.n_steps = 1
+    io.n_prop = 2
+    assert hip.glabc_propose(A.ALGO_GLOBALMCMC, C.byref(g), C.byref(g), C.byref(cs), C.byref(run), C.byref(io), None) == -4  # GlobalMCMC: one candidate
+    empty = engine.ChainBatch(torch.zeros(4, 2), torch.zeros(4, 2), dev)
+    es = empty.struct()
+    es.n_chains = 0
+    buf = torch.zeros(64, device=dev)
+    io = A.StepIO(3, 2, 2, 0, *([buf.data_ptr()] * 2), None, *([buf.data_ptr()] * 8), None)
+    assert hip.glabc_propose(A.ALGO_GLMCMC, C.byref(g), C.byref(g), C.byref(es), C.byref(run), C.byref(io), None) == 0       # zero chains: nothing to do
+    assert hip.glabc_select(A.ALGO_GLMCMC, C.byref(g), C.byref(es), C.byref(run), C.byref(io), None) == 0
+    assert hip.glabc_model_simulate(None, buf.data_ptr(), None, 4, 0, 0, buf.data_ptr(), None) == -1
