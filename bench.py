@@ -225,6 +225,48 @@ def bench_glmcmc_nf(args):
     print(json.dumps(out), flush=True)
 
 
+def cpu_baseline_callback(n, iters, seconds_target=12.0):
+    """The callback workload on the host: the CPU checker's split-phase twins (oracle_propose / oracle_select) around the SAME
+    plain-torch Model evaluated on CPU tensors -- a batched-ATen CPU path of the loop bench_callback times on the GPU."""
+    import oracle_lib
+    from glabcmcmc_amd import _capi as A, distribution
+    from glabcmcmc_amd.examples.UserModel import TorchMixture
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    L = oracle_lib.load()
+    N = NBATCH
+    model = TorchMixture(2, EPS)
+    lp = distribution.DiagGaussian(2, torch.zeros(2), torch.log(torch.tensor([0.35, 0.35]))).descriptor()
+    ip = distribution.DiagGaussian(2, torch.zeros(2), torch.zeros(2)).descriptor()
+    R = N * n
+    hc = oracle_lib.HostChains(np.zeros((n, 2), np.float32), (0.05 ** 0.5) * np.random.default_rng(0).standard_normal((n, 2)).astype(np.float32))
+    cs = hc.struct()
+    f32 = np.float32
+    buf = dict(theta_prop=np.zeros((R, 2), f32), log_q=np.zeros(R, f32), log_u=np.zeros(n, f32), u_res=np.zeros(n, np.float64),
+               is_global=np.zeros(n, np.int32), prior_cur=np.zeros(n, f32), kern_cur=np.zeros(n, f32))
+    buf["prior_cur"][:] = model.prior_log_prob(torch.from_numpy(hc.theta.T.copy())).numpy()
+    buf["kern_cur"][:] = model.calculate_log_kernel(torch.from_numpy(hc.y.T.copy())).numpy()
+    io = A.StepIO(N, 2, 2, 0, buf["theta_prop"].ctypes.data, buf["log_q"].ctypes.data, None, buf["log_u"].ctypes.data,
+                  buf["u_res"].ctypes.data, buf["is_global"].ctypes.data, None, None, None, buf["prior_cur"].ctypes.data,
+                  buf["kern_cur"].ctypes.data, None)
+    done, t0 = 0, time.perf_counter()
+    while done < iters and (done < 5 or time.perf_counter() - t0 < seconds_target):
+        run, keep = oracle_lib.make_run(seed=1, step0=1 + done, n_steps=1, gf=GF, batch=N)
+        assert L.oracle_propose(0, C.byref(lp), C.byref(ip), C.byref(cs), C.byref(run), C.byref(io)) == 0
+        th = torch.from_numpy(buf["theta_prop"])
+        prior = model.prior_log_prob(th).numpy().astype(f32)
+        y = model.generate_samples(th).contiguous()
+        kern = model.calculate_log_kernel(y).numpy().astype(f32)
+        yn = y.numpy()
+        io.prior_prop, io.y_prop, io.kern_prop = prior.ctypes.data, yn.ctypes.data, kern.ctypes.data
+        assert L.oracle_select(0, C.byref(ip), C.byref(cs), C.byref(run), C.byref(io)) == 0
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * done / dt, "unit": "chain-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle_propose -> examples/UserModel.TorchMixture on CPU tensors (torch, %d threads) -> oracle_select, %d chains x "
+                      "%d iterations of the callback workload" % (cores, n, done)}
+
+
 def bench_callback(args):
     """SURVEY.md 8b-ii, the reference's plug-in API: GLMCMC (iSIR N=5, gf 0.9) with a user Model that is a plain-torch
     object -- no descriptor, so every iteration is glabc_propose -> the Model's callbacks on a (5 * chains, 2) batch ->
@@ -242,10 +284,14 @@ def bench_callback(args):
     mom = engine.Moments(n, 2, dev)
     step_idx = [0]
 
+    st_last = {}
+
     def one_step():
-        st = {}
+        st = st_last
+        st.clear()
         GLMCMC(model, K + 1, state["theta"], state["y"], lp, None, GF, ip, N, seed=20261003 + step_idx[0], record_history=False,
-               stats=mom, verbose=False, state_out=st, sentinel_redraw=not args.no_sentinel)
+               stats=mom, verbose=False, state_out=st, sentinel_redraw=not args.no_sentinel,
+               graph="auto" if args.no_sentinel and not args.no_graph else False)
         ch = st["chains"]
         state["theta"], state["y"] = ch.theta.t(), ch.y.t()            # stay on the device (prepare() copies through the host)
         step_idx[0] += 1
@@ -305,7 +351,8 @@ def bench_callback(args):
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "GLMCMC iSIR N=5 gf=0.9, examples/UserModel.TorchMixture (plain torch, no descriptor) eps=0.05 "
                                   "d=2: glabc_propose -> callbacks -> glabc_select per iteration", "chains_per_gpu": n,
-                      "iters_per_step": K, "batch_size": N, "sentinel_redraw": not args.no_sentinel},
+                      "iters_per_step": K, "batch_size": N, "sentinel_redraw": not args.no_sentinel,
+                      "hip_graph": bool(st_last.get("graph"))},
            "us_per_iteration": elapsed / (args.steps * K) * 1e6,
            "esjd_mean": float(esjd[ok].double().mean()),
            "mean_theta_sq": float(mom.second_moment().diagonal(dim1=1, dim2=2).mean()), "analytic_mean_theta_sq": 2.081014,
@@ -315,6 +362,8 @@ def bench_callback(args):
                         "algorithmic_bytes_per_launch": bytes_prop + bytes_sel,
                         "note": "the two HIP kernels take %.0f us of the %.0f us of an iteration; the rest is the Model's "
                                 "~10 torch kernels and launch latency" % ((ms_prop + ms_sel) * 1e3, elapsed / (args.steps * K) * 1e6)}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_callback(n, 400)
     print(json.dumps(out), flush=True)
 
 
@@ -334,6 +383,8 @@ def main():
     ap.add_argument("--batch", type=int, default=NBATCH, help="iSIR batch size N (default 5 = BASELINE configs[1]); above 16 the "
                     "wide kernel of glabc_wide.hip runs")
     ap.add_argument("--couplings", type=int, default=8, help="nf workload: number of couplings")
+    ap.add_argument("--no-graph", action="store_true", help="callback workload: launch every iteration instead of replaying a "
+                    "captured hipGraph (only an iteration without the sentinel check can be captured)")
     ap.add_argument("--no-sentinel", action="store_true", help="callback workload: skip the GLMCMC.py:92-93 redraw check "
                     "(one device->host sync per iteration)")
     ap.add_argument("--rehearse-gloo", action="store_true",

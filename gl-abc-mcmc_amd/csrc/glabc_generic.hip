@@ -66,6 +66,7 @@ struct GenArgs {
     int64_t n_chains, chain0, stride;
     // run
     uint32_t seed_lo, seed_hi, step;
+    const uint32_t* step_dev;     // glabc_run.step0_device: the iteration index lives on the device (graph replay)
     float gf;
     const float* gf_chain;
     float* history;
@@ -115,10 +116,11 @@ __global__ void __launch_bounds__(256) propose_kernel(const GenArgs a)
     const uint32_t c0 = (uint32_t)gid, c1 = (uint32_t)(gid >> 32);
     const int D = a.theta_dim, DP = D + (D & 1), ND = a.noise_dim;
     const int SPP = (DP + ND + 3) / 4;
+    const uint32_t step = a.step_dev ? *a.step_dev : a.step;
 
     bool is_global = true;
     if (j == 0) {                                                           // the step head, Philox slot 0
-        const glabc_u32x4 h = glabc_philox4x32_10(c0, c1, a.step, 0u, a.seed_lo, a.seed_hi);
+        const glabc_u32x4 h = glabc_philox4x32_10(c0, c1, step, 0u, a.seed_lo, a.seed_hi);
         const float ub = glabc_uniform_f32(h.v[0]), ua = glabc_uniform_f32(h.v[1]);
         const float gf = a.gf_chain ? a.gf_chain[c] : a.gf;
         is_global = ub < gf;                                                // GLMCMC.py:59 / GlobalMCMC.py:39
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(256) propose_kernel(const GenArgs a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         if (b < SPP) {
-            const glabc_u32x4 o = glabc_philox4x32_10(c0, c1, a.step, (uint32_t)(1 + j * SPP + b), a.seed_lo, a.seed_hi);
+            const glabc_u32x4 o = glabc_philox4x32_10(c0, c1, step, (uint32_t)(1 + j * SPP + b), a.seed_lo, a.seed_hi);
             float nrm[4];
             glabc_normal_pair(o.v[0], o.v[1], &nrm[0], &nrm[1]);
             glabc_normal_pair(o.v[2], o.v[3], &nrm[2], &nrm[3]);
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(256) propose_kernel(const GenArgs a)
         }
     }
     for (int b = 2; b < SPP; ++b) {                                         // simulator normals only
-        const glabc_u32x4 o = glabc_philox4x32_10(c0, c1, a.step, (uint32_t)(1 + j * SPP + b), a.seed_lo, a.seed_hi);
+        const glabc_u32x4 o = glabc_philox4x32_10(c0, c1, step, (uint32_t)(1 + j * SPP + b), a.seed_lo, a.seed_hi);
         float nrm[4];
         glabc_normal_pair(o.v[0], o.v[1], &nrm[0], &nrm[1]);
         glabc_normal_pair(o.v[2], o.v[3], &nrm[2], &nrm[3]);
@@ -187,8 +189,8 @@ __global__ void __launch_bounds__(256) redraw_kernel(const GenArgs a)
     float e[GD];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const glabc_u32x4 o = glabc_philox4x32_10(c0, c1, a.step, GLABC_SLOT_REDRAW + (uint32_t)(2 * a.redraw_round + b), a.seed_lo,
-                                                  a.seed_hi);
+        const glabc_u32x4 o = glabc_philox4x32_10(c0, c1, a.step_dev ? *a.step_dev : a.step,
+                                                  GLABC_SLOT_REDRAW + (uint32_t)(2 * a.redraw_round + b), a.seed_lo, a.seed_hi);
         float nrm[4];
         glabc_normal_pair(o.v[0], o.v[1], &nrm[0], &nrm[1]);
         glabc_normal_pair(o.v[2], o.v[3], &nrm[2], &nrm[3]);
@@ -285,8 +287,11 @@ __global__ void __launch_bounds__(256) select_kernel(const GenArgs a)
         if (a.n_moves) a.n_moves[c] += 1u;
         a.is_global[c] |= 2;
     }
-    if (a.history)
-        for (int j = 0; j < D; ++j) a.history[j * a.hist_stride + c] = a.theta[j * a.stride + c];     // GLMCMC.py:89,104
+    if (a.history) {                                                                      // GLMCMC.py:89,104
+        // row (index - step0) when the iteration index is read from the device (one captured graph, many replays)
+        float* row = a.history + (a.step_dev ? (int64_t)(*a.step_dev - a.step) * D * a.hist_stride : 0);
+        for (int j = 0; j < D; ++j) row[j * a.hist_stride + c] = a.theta[j * a.stride + c];
+    }
     if (isir) {
         a.log_w[c] = log_w;
         a.flags[c] = flags;
@@ -415,6 +420,7 @@ static int pack_common(int algo, const glabc_dist* local, const glabc_dist* glob
     a->seed_lo = (uint32_t)r->seed;
     a->seed_hi = (uint32_t)(r->seed >> 32);
     a->step = r->step0;
+    a->step_dev = r->step0_device;
     a->gf = r->global_frequency;
     a->gf_chain = r->global_frequency_per_chain;
     a->history = r->history;

@@ -675,6 +675,7 @@ static int check_run(const glabc_model* m, const glabc_dist* local, const glabc_
         if (r->tape->n_prop < 1 || (isir && r->tape->n_prop < r->batch_size)) return GLABC_ERR_ARG;
     }
     if ((uint64_t)r->step0 + (uint64_t)r->n_steps > 0xFFFFFFFFull) return GLABC_ERR_ARG;
+    if (r->step0_device) return GLABC_ERR_ARG;                  // the split-phase entry points only
     return GLABC_OK;
 }
 

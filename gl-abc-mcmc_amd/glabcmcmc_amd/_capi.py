@@ -211,6 +211,7 @@ class Run(C.Structure):
         ("tape", C.POINTER(Tape)),
         ("lanes_per_chain", C.c_int32),
         ("debug_flags", C.c_int32),
+        ("step0_device", C.c_void_p),
         ("global_frequency_per_chain", C.c_void_p),
     ]
 

@@ -18,6 +18,7 @@ class TorchMixture:
         self.theta_dim = self.y_dim = theta_dim
         self.epsilon = epsilon
         self.y_obs = torch.full((1, theta_dim), 1.5)
+        self._y_obs_on = {}                      # y_obs per device: no host -> device copy inside the sampler loop
 
     def generate_samples(self, theta, num_samples=1):
         theta = theta.reshape(-1, self.theta_dim)
@@ -29,7 +30,9 @@ class TorchMixture:
 
     def discrepancy(self, y):
         y = y.reshape(-1, self.y_dim)
-        return ((y - self.y_obs.to(y.device)) ** 2).sum(1).sqrt()
+        if y.device not in self._y_obs_on:
+            self._y_obs_on[y.device] = self.y_obs.to(y.device)
+        return ((y - self._y_obs_on[y.device]) ** 2).sum(1).sqrt()
 
     def calculate_log_kernel(self, y, epsilon=None):
         e = self.discrepancy(y) / (self.epsilon if epsilon is None else epsilon)

@@ -86,16 +86,24 @@ class ModelCallbacks:
         return t.detach().to(device=self.device, dtype=torch.float32).reshape(rows, -1).contiguous()
 
     def _call(self, fn):
-        """fn(on_cuda: bool).  'auto': a Model written against CPU tensors (the reference's own examples/Mixture.py
-        mixes its CPU constants into the arithmetic) raises on CUDA tensors -- then, and from then on, it gets CPU copies."""
-        if self.auto and self.where != "cpu":
-            try:
-                out = fn(True)
-                self.where = "cuda"
-                return out
-            except (RuntimeError, TypeError, ValueError):
-                self.where = "cpu"
-        return fn(self.where == "cuda")
+        """fn(on_cuda: bool)"""
+        return fn(self.where != "cpu")
+
+    def probe(self, theta_rows, y_rows):
+        """'auto': decide once, before the loop, where the callbacks run.  A Model written against CPU tensors (the
+        reference's own examples/Mixture.py mixes its CPU constants into the arithmetic) raises on CUDA tensors; it then
+        gets CPU copies of every batch.  All three callbacks are tried on a few rows; the decision is final."""
+        if not self.auto:
+            return
+        try:
+            self.where = "cuda"
+            th = theta_rows[:2].contiguous()
+            self.prior(th)
+            noise = torch.zeros(th.shape[0], self.noise_dim, device=th.device) if self.noise_dim else None
+            self.kernel(self.simulate(th, noise))
+            self.kernel(y_rows[:2].contiguous())
+        except (RuntimeError, TypeError, ValueError):
+            self.where = "cpu"
 
     def prior(self, theta):
         rows = theta.shape[0]
@@ -145,9 +153,15 @@ class ProposalCallbacks:
 
 def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_Proposal, filelocation, global_frequency,
         batch_size, csv_variant, *, seed=None, device=None, chain0=0, record_history=True, stats=None, return_device=False,
-        verbose=True, state_out=None, callback_device="auto", sentinel_redraw=True, max_redraws=100000, progress=None):
+        verbose=True, state_out=None, callback_device="auto", sentinel_redraw=True, max_redraws=100000, progress=None,
+        graph="auto"):
     """GLMCMC (algo = _capi.ALGO_GLMCMC, GLMCMC.py:24-137) or GlobalMCMC (_capi.ALGO_GLOBALMCMC, GlobalMCMC.py:6-98) with
-    the Model -- and, if need be, the proposals -- as callbacks.  Same return value and side effects as the fused path."""
+    the Model -- and, if need be, the proposals -- as callbacks.  Same return value and side effects as the fused path.
+
+    graph: 'auto' | True | False.  An iteration whose work never visits the host -- descriptor proposals, callbacks on CUDA
+    tensors, no sentinel check (GlobalMCMC, or sentinel_redraw=False) -- is captured ONCE as a hipGraph (torch.cuda.graph:
+    the two HIP kernels with the iteration index in device memory, glabc_run.step0_device, plus the Model's own kernels) and
+    replayed; 'auto' falls back to launching eagerly when the capture is not possible (e.g. a callback that synchronises)."""
     lib = _capi.lib()
     dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
     n, d, yd = chains.n, chains.d, chains.yd
@@ -173,6 +187,7 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     u_res = torch.zeros(n, dtype=torch.float64, device=dev)
     is_global = torch.zeros(n, dtype=torch.int32, device=dev)
     n_redrawn = torch.zeros(1, dtype=torch.int32, device=dev)
+    model.probe(chains.theta.t(), chains.y.t())
     # callbacks of the initial state (GLMCMC.py:52-55): carried from here on by glabc_select
     prior_cur = model.prior(chains.theta.t().contiguous()).clone()
     kern_cur = model.kernel(chains.y.t().contiguous()).clone()
@@ -196,55 +211,104 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     gp = C.byref(global_desc) if global_desc is not None else None
     row0_local = None
 
-    with torch.cuda.device(dev):
-        for i in range(1, num_ite):
+    keep = {}                                              # tensors whose addresses the current StepIO holds
+
+    def iteration(i):
+        """one iteration on torch's current stream; i = None: the index is read from step_t on the device (graph)"""
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if i is not None:
             run_.step0 = i
             run_.history = hist_ptr + i * hist_row_bytes if hist is not None else None
-            _capi.check(lib.glabc_propose(algo, lp, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_propose")
-            if global_cb is not None or local_cb is not None:
-                glob_rows = (is_global != 0)
-                if global_cb is not None:                                  # Importance_Proposal.forward(batch_size), GLMCMC.py:66
-                    z, lq = global_cb.forward(R)
-                    if local_cb is None:                                   # keep the kernel's local-move rows
-                        keep = torch.zeros(R, dtype=torch.bool, device=dev)
-                        keep[:n] = ~glob_rows
-                        z = torch.where(keep.view(-1, 1), theta_prop, z)
-                    theta_prop.copy_(z)
-                    log_q.copy_(lq)
-                if local_cb is not None:                                   # Local_Proposal.sample(1) + Theta_old, GLMCMC.py:91
-                    row0_local = local_cb.sample(n) + chains.theta.t()
-                    theta_prop[:n] = torch.where(glob_rows.view(-1, 1), theta_prop[:n], row0_local)
-            prior_prop = model.prior(theta_prop)                           # GLMCMC.py:74,92,96
-            io.prior_prop = prior_prop.data_ptr()
-            if sentinel_redraw and algo == _capi.ALGO_GLMCMC:              # GLMCMC.py:92-93
-                for rnd in range(1, max_redraws + 1):
-                    if local_cb is None:
-                        n_redrawn.zero_()
-                        _capi.check(lib.glabc_propose_redraw(lp, C.byref(cs), C.byref(run_), C.byref(io), rnd,
-                                                             n_redrawn.data_ptr(), stream), "glabc_propose_redraw")
-                        if int(n_redrawn.item()) == 0:
-                            break
-                        prior_prop[:n] = model.prior(theta_prop[:n])
-                    else:
-                        again = (is_global == 0) & (prior_prop[:n] == SENTINEL)
-                        k = int(again.sum().item())
-                        if k == 0:
-                            break
-                        theta_prop[:n][again] = local_cb.sample(k) + chains.theta.t()[again]
-                        prior_prop[:n] = model.prior(theta_prop[:n])
+        _capi.check(lib.glabc_propose(algo, lp, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_propose")
+        if global_cb is not None or local_cb is not None:
+            glob_rows = (is_global != 0)
+            if global_cb is not None:                                  # Importance_Proposal.forward(batch_size), GLMCMC.py:66
+                z, lq = global_cb.forward(R)
+                if local_cb is None:                                   # keep the kernel's local-move rows
+                    keep_rows = torch.zeros(R, dtype=torch.bool, device=dev)
+                    keep_rows[:n] = ~glob_rows
+                    z = torch.where(keep_rows.view(-1, 1), theta_prop, z)
+                theta_prop.copy_(z)
+                log_q.copy_(lq)
+            if local_cb is not None:                                   # Local_Proposal.sample(1) + Theta_old, GLMCMC.py:91
+                row0_local = local_cb.sample(n) + chains.theta.t()
+                theta_prop[:n] = torch.where(glob_rows.view(-1, 1), theta_prop[:n], row0_local)
+        prior_prop = model.prior(theta_prop)                           # GLMCMC.py:74,92,96
+        io.prior_prop = prior_prop.data_ptr()
+        if sentinel_redraw and algo == _capi.ALGO_GLMCMC:              # GLMCMC.py:92-93
+            for rnd in range(1, max_redraws + 1):
+                if local_cb is None:
+                    n_redrawn.zero_()
+                    _capi.check(lib.glabc_propose_redraw(lp, C.byref(cs), C.byref(run_), C.byref(io), rnd,
+                                                         n_redrawn.data_ptr(), stream), "glabc_propose_redraw")
+                    if int(n_redrawn.item()) == 0:
+                        break
+                    prior_prop[:n] = model.prior(theta_prop[:n])
                 else:
-                    raise RuntimeError("the local proposal keeps landing where prior_log_prob returns the sentinel "
-                                       "7*log(1e-10) (GLMCMC.py:92-93) after %d redraws" % max_redraws)
-            y_prop = model.simulate(theta_prop, sim_noise)                 # GLMCMC.py:71,94
-            if y_prop.shape[1] != yd:
-                raise ValueError("generate_samples returned %d columns, Initial_y has %d" % (y_prop.shape[1], yd))
-            kern_prop = model.kernel(y_prop)                               # GLMCMC.py:72,96
-            io.y_prop, io.kern_prop = y_prop.data_ptr(), kern_prop.data_ptr()
-            q_cur = None
-            if global_cb is not None:                                      # Importance_Proposal.log_prob(Theta_old), GLMCMC.py:63
-                q_cur = global_cb.log_prob(chains.theta.t().contiguous())
-                io.q_cur = q_cur.data_ptr()
-            _capi.check(lib.glabc_select(algo, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_select")
+                    again = (is_global == 0) & (prior_prop[:n] == SENTINEL)
+                    k = int(again.sum().item())
+                    if k == 0:
+                        break
+                    theta_prop[:n][again] = local_cb.sample(k) + chains.theta.t()[again]
+                    prior_prop[:n] = model.prior(theta_prop[:n])
+            else:
+                raise RuntimeError("the local proposal keeps landing where prior_log_prob returns the sentinel "
+                                   "7*log(1e-10) (GLMCMC.py:92-93) after %d redraws" % max_redraws)
+        y_prop = model.simulate(theta_prop, sim_noise)                 # GLMCMC.py:71,94
+        if y_prop.shape[1] != yd:
+            raise ValueError("generate_samples returned %d columns, Initial_y has %d" % (y_prop.shape[1], yd))
+        kern_prop = model.kernel(y_prop)                               # GLMCMC.py:72,96
+        io.y_prop, io.kern_prop = y_prop.data_ptr(), kern_prop.data_ptr()
+        keep.update(prior=prior_prop, y=y_prop, kern=kern_prop)
+        if global_cb is not None:                                      # Importance_Proposal.log_prob(Theta_old), GLMCMC.py:63
+            keep["q"] = global_cb.log_prob(chains.theta.t().contiguous())
+            io.q_cur = keep["q"].data_ptr()
+        _capi.check(lib.glabc_select(algo, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_select")
+
+    capturable = (local_cb is None and global_cb is None and not (sentinel_redraw and algo == _capi.ALGO_GLMCMC)
+                  and progress is None)
+    if graph is True and not capturable:
+        raise ValueError("graph=True needs descriptor proposals and no sentinel check (sentinel_redraw=False or GlobalMCMC)")
+    use_graph = capturable and graph in ("auto", True) and num_ite > 8
+    with torch.cuda.device(dev):
+        i = 1
+        if use_graph:
+            # three eager iterations (they also settle where the callbacks run), then one captured iteration replayed
+            for _ in range(3):
+                iteration(i)
+                i += 1
+            use_graph = model.where != "cpu"
+        if use_graph:
+            step_t = torch.tensor([i], dtype=torch.int32, device=dev)          # the iteration index, on the device
+            run_.step0, run_.step0_device = 1, step_t.data_ptr()
+            run_.history = hist_ptr + hist_row_bytes if hist is not None else None   # row 0 of `history` = iteration 1
+            g = torch.cuda.CUDAGraph()
+            try:
+                side = torch.cuda.Stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):                                   # warm the captured form once (step_t advances)
+                    iteration(None)
+                    step_t.add_(1)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                i += 1
+                with torch.cuda.graph(g):
+                    iteration(None)
+                    step_t.add_(1)
+            except Exception:                                                   # not capturable after all: launch eagerly
+                if graph is True:
+                    raise
+                torch.cuda.synchronize(dev)
+                g = None
+                i = int(step_t.item())
+            run_.step0_device = None
+            if g is not None:
+                for _ in range(i, num_ite):
+                    g.replay()
+                i = num_ite
+                if state_out is not None:
+                    state_out["graph"] = True
+        for i in range(i, num_ite):
+            iteration(i)
             if progress is not None:
                 progress(i)
     if stats is not None:
@@ -322,6 +386,7 @@ def run_glmala(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad, fileloc
     log_u = torch.zeros(n, **f32)
     u_res = torch.zeros(n, dtype=torch.float64, device=dev)
     is_global = torch.zeros(n, dtype=torch.int32, device=dev)
+    model.probe(chains.theta.t(), chains.y.t())
     prior_cur = model.prior(chains.theta.t().contiguous()).clone()
     kern_cur = model.kernel(chains.y.t().contiguous()).clone()
     grad = torch.zeros(n, d, dtype=torch.float64, device=dev)                                    # grad_logABC_Theta_old, :146

@@ -162,6 +162,10 @@ typedef struct glabc_run {
     int32_t lanes_per_chain;       /* launch geometry only, never changes results: 0 = choose, or 1 / 2 / 4 lanes cooperating on
                                       one chain's batch_size proposals (8 / 16 / 32 / 64 when batch_size > GLABC_MAX_BATCH) */
     int32_t debug_flags;           /* 0, or GLABC_DEBUG_* bits: execution strategy only, never changes results */
+    const uint32_t* step0_device;  /* glabc_propose / glabc_propose_redraw / glabc_select only: NULL, or a DEVICE word holding the
+                                      iteration index of this call.  The kernels then read the index from it (Philox counter
+                                      word 2) and write the Theta_Re row (index - step0) of `history`, so ONE captured hipGraph
+                                      of an iteration can be replayed while the word is incremented between replays */
     const float* global_frequency_per_chain;   /* NULL, or device array [n_chains] that replaces global_frequency chain by
                                       chain -- a hyper-parameter grid (examples/Mixture_hyper.py:24) is then one launch.
                                       glabc_glmcmc_steps / glabc_globalmcmc_steps only */

@@ -1629,9 +1629,10 @@ ORACLE_API int oracle_propose(int algo, const glabc_dist* local, const glabc_dis
     const int d = io->theta_dim, nd = io->noise_dim, N = io->n_prop;
     if ((local || global) && d > GLABC_MAX_DIM) return GLABC_ERR_DIM;
     const int64_t C = c->n_chains;
+    const uint32_t step = run->step0_device ? *run->step0_device : run->step0;     /* glabc_run.step0_device */
     for (int64_t i = 0; i < C; ++i) {
         const uint64_t chain = (uint64_t)(c->chain0 + i);
-        glabc_u32x4 h = glabc_philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), run->step0, 0u, (uint32_t)run->seed,
+        glabc_u32x4 h = glabc_philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), step, 0u, (uint32_t)run->seed,
                                             (uint32_t)(run->seed >> 32));
         const float gf = run->global_frequency_per_chain ? run->global_frequency_per_chain[i] : run->global_frequency;
         const int is_global = glabc_uniform_f32(h.v[0]) < gf;                   /* GLMCMC.py:59 */
@@ -1642,7 +1643,7 @@ ORACLE_API int oracle_propose(int algo, const glabc_dist* local, const glabc_dis
             const int64_t r = (int64_t)j * C + i;
             const glabc_dist* g = (j == 0 && !is_global) ? local : global;
             float e[GLABC_MAX_DIM] = {0}, z[GLABC_MAX_DIM], lq = 0.0f;
-            candidate_draws(run->seed, chain, run->step0, j, d, nd, g && g->kind == GLABC_DIST_UNIFORM, e,
+            candidate_draws(run->seed, chain, step, j, d, nd, g && g->kind == GLABC_DIST_UNIFORM, e,
                             io->sim_noise ? io->sim_noise + r * nd : NULL);
             if (!g) continue;                                                   /* the caller fills these rows */
             rc = prop_forward(g, e, z, &lq);                                    /* GLMCMC.py:66 / :91 */
@@ -1672,7 +1673,8 @@ ORACLE_API int oracle_propose_redraw(const glabc_dist* local, const glabc_chains
         const uint64_t chain = (uint64_t)(c->chain0 + i);
         float e[GLABC_MAX_DIM], z[GLABC_MAX_DIM], lq;
         for (int b = 0; b < 2; ++b) {
-            glabc_u32x4 o = glabc_philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), run->step0,
+            glabc_u32x4 o = glabc_philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32),
+                                                run->step0_device ? *run->step0_device : run->step0,
                                                 GLABC_SLOT_REDRAW + (uint32_t)(2 * round + b), (uint32_t)run->seed,
                                                 (uint32_t)(run->seed >> 32));
             float nrm[4];
@@ -1754,8 +1756,10 @@ ORACLE_API int oracle_select(int algo, const glabc_dist* global, const glabc_cha
             io->is_global[i] |= 2;
         }
         /* Theta_Re row and streaming sums, any theta_dim */
-        if (run->history)
-            for (int k = 0; k < d; ++k) run->history[k * run->hist_stride + i] = c->theta[k * c->stride + i];
+        if (run->history) {
+            float* row = run->history + (run->step0_device ? (int64_t)(*run->step0_device - run->step0) * d * run->hist_stride : 0);
+            for (int k = 0; k < d; ++k) row[k * run->hist_stride + i] = c->theta[k * c->stride + i];
+        }
         if (run->moments) {
             const glabc_moments* m = run->moments;
             int k = 0;

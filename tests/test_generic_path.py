@@ -518,3 +518,27 @@ def test_hip_split_phase_entry_points_validate(hip):
     assert hip.glabc_propose(A.ALGO_GLMCMC, C.byref(g), C.byref(g), C.byref(es), C.byref(run), C.byref(io), None) == 0       # zero chains: nothing to do
     assert hip.glabc_select(A.ALGO_GLMCMC, C.byref(g), C.byref(es), C.byref(run), C.byref(io), None) == 0
     assert hip.glabc_model_simulate(None, buf.data_ptr(), None, 4, 0, 0, buf.data_ptr(), None) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["globalmcmc_philox_bench", "glmcmc_philox_n8"])
+def test_hip_graph_replay_walks_the_reference_chains(hip, name):
+    """One captured hipGraph of an iteration (the two HIP kernels with the iteration index in device memory + the Model's
+    kernels), replayed: same chains as launching every iteration -- i.e. the reference's golden chains, bit for bit."""
+    import glabcmcmc_amd as g_
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, local, glob = descriptors(cfg, g)
+    T = min(cfg["T"], 300)
+    th0, y0 = torch.from_numpy(g["theta0"]), torch.from_numpy(g["y0"])
+    st = {}
+    kw = dict(seed=cfg["seed"], chain0=cfg.get("chain0", 0), verbose=False, graph=True, state_out=st)
+    if str(g["algo"]) == "glmcmc":
+        out = g_.GLMCMC(ProtocolModel(model), T + 1, th0, y0, FixedDescriptor(local), None, cfg["gf"], FixedDescriptor(glob),
+                        cfg["N"], sentinel_redraw=False, **kw)
+    else:
+        out = g_.GlobalMCMC(ProtocolModel(model), T + 1, th0, y0, FixedDescriptor(glob), None, cfg["gf"], FixedDescriptor(local), **kw)
+    assert st.get("graph") is True
+    same = bits(out.numpy()) == bits(g["chains"][:T + 1])
+    assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
+    assert (st["chains"].n_moves.cpu().numpy() > 0).any()
