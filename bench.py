@@ -225,6 +225,52 @@ def bench_glmcmc_nf(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_aglmcmc(args):
+    """SURVEY.md 8(f) f-4 end to end: AGLMCMC (AGLMCMC.py:44-289; adaptive KDE proposal, annealed threshold) at 65 536 chains
+    sharing one density: per iteration KernelDensity.log_prob of the current states + the pool-iSIR / RW-MH kernel, per pool
+    refresh the quantile update, KDE refit, 4x oversampled redraw, pool weights."""
+    import glabcmcmc_amd as g
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    import warnings
+    torch.cuda.set_device(0)
+    n, K, N, step_size = args.chains, min(args.iters, 60), NBATCH, 20
+    m = Mixture_set(EPS)
+    lp = g.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35])))
+    isir = g.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.5, 0.5]))
+    torch.manual_seed(0)
+    theta0 = torch.zeros(n, 2)
+    y0 = (0.05 ** 0.5) * torch.randn(n, 2)
+    st = {}
+
+    def one_step(i):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            g.AGLMCMC(m, K + 1, theta0, y0, lp, isir, None, 0.9, step_size, N, 0.8, 0.2, seed=50 + i, return_device=True,
+                      verbose=False, state_out=st)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    per_iter = elapsed / (args.steps * K)
+    out = {"metric": "MH accept-steps/sec, AGLMCMC end to end (adaptive KDE proposal), 65 536 chains",
+           "value": float(n) / per_iter, "unit": "chain-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "AGLMCMC N=5 step_size=%d gf=0.9 alpha=0.8 hat_eps_T=0.2, Mixture_set eps=0.05, one KDE shared by "
+                                  "the chains (8192 training rows)" % step_size, "chains_per_gpu": n, "iters_per_step": K},
+           "iterations_per_s": 1.0 / per_iter, "us_per_iteration": per_iter * 1e6,
+           "kde_refits_last_step": st.get("num_train"),
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "kernel": "kde_log_prob_kernel<2> (dense points x centres logsumexp)", "kernel_ms": None,
+                        "note": "whole-loop rate; the dominant kernel is VALU-bound O(points x centres) work, rated by --workload kde"}}
+    print(json.dumps(out), flush=True)
+
+
 def cpu_baseline_callback(n, iters, seconds_target=12.0):
     """The callback workload on the host: the CPU checker's split-phase twins (oracle_propose / oracle_select) around the SAME
     plain-torch Model evaluated on CPU tensors -- a batched-ATen CPU path of the loop bench_callback times on the GPU."""
@@ -390,7 +436,7 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the multi-rank control flow on ONE GPU: every rank uses cuda:0 and the collectives "
                          "run on gloo with CPU copies (numbers are meaningless; RCCL needs one GPU per rank)")
-    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback", "glmcmc_nf"],
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback", "glmcmc_nf", "aglmcmc"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
@@ -402,6 +448,8 @@ def main():
         return bench_callback(args)
     if args.workload == "glmcmc_nf":
         return bench_glmcmc_nf(args)
+    if args.workload == "aglmcmc":
+        return bench_aglmcmc(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

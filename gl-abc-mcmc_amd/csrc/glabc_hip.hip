@@ -1132,7 +1132,7 @@ __attribute__((visibility("default"))) int glabc_esjd(const float* history, int6
                                                       int64_t n_chains, int64_t stride, float* esjd_out, void* stream)
 {
     if (!history || !esjd_out) return GLABC_ERR_NULL;
-    if (theta_dim < 1 || theta_dim > 4) return GLABC_ERR_DIM;
+    if (theta_dim < 1 || theta_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
     if (n_rows < 2 || n_chains < 0 || stride < n_chains) return GLABC_ERR_ARG;
     if (n_chains == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -1142,6 +1142,10 @@ __attribute__((visibility("default"))) int glabc_esjd(const float* history, int6
     case 2: hipLaunchKernelGGL(esjd_kernel<2>, grid, block, 0, s, history, n_rows, n_chains, stride, esjd_out); break;
     case 3: hipLaunchKernelGGL(esjd_kernel<3>, grid, block, 0, s, history, n_rows, n_chains, stride, esjd_out); break;
     case 4: hipLaunchKernelGGL(esjd_kernel<4>, grid, block, 0, s, history, n_rows, n_chains, stride, esjd_out); break;
+    case 5: hipLaunchKernelGGL(esjd_kernel<5>, grid, block, 0, s, history, n_rows, n_chains, stride, esjd_out); break;
+    case 6: hipLaunchKernelGGL(esjd_kernel<6>, grid, block, 0, s, history, n_rows, n_chains, stride, esjd_out); break;
+    case 7: hipLaunchKernelGGL(esjd_kernel<7>, grid, block, 0, s, history, n_rows, n_chains, stride, esjd_out); break;
+    case 8: hipLaunchKernelGGL(esjd_kernel<8>, grid, block, 0, s, history, n_rows, n_chains, stride, esjd_out); break;
     }
     return finish_launch();
 }
@@ -1150,7 +1154,7 @@ __attribute__((visibility("default"))) int glabc_moments_esjd(const glabc_moment
                                                               int64_t n_chains, int64_t stride, float* esjd_out, void* stream)
 {
     if (!moments || !moments->sum_jump || !esjd_out) return GLABC_ERR_NULL;
-    if (theta_dim < 1 || theta_dim > 4) return GLABC_ERR_DIM;
+    if (theta_dim < 1 || theta_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
     if (n_steps < 1 || n_chains < 0 || stride < n_chains) return GLABC_ERR_ARG;
     if (n_chains == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -1160,6 +1164,10 @@ __attribute__((visibility("default"))) int glabc_moments_esjd(const glabc_moment
     case 2: hipLaunchKernelGGL(moments_esjd_kernel<2>, grid, block, 0, s, moments->sum_jump, n_steps, n_chains, stride, esjd_out); break;
     case 3: hipLaunchKernelGGL(moments_esjd_kernel<3>, grid, block, 0, s, moments->sum_jump, n_steps, n_chains, stride, esjd_out); break;
     case 4: hipLaunchKernelGGL(moments_esjd_kernel<4>, grid, block, 0, s, moments->sum_jump, n_steps, n_chains, stride, esjd_out); break;
+    case 5: hipLaunchKernelGGL(moments_esjd_kernel<5>, grid, block, 0, s, moments->sum_jump, n_steps, n_chains, stride, esjd_out); break;
+    case 6: hipLaunchKernelGGL(moments_esjd_kernel<6>, grid, block, 0, s, moments->sum_jump, n_steps, n_chains, stride, esjd_out); break;
+    case 7: hipLaunchKernelGGL(moments_esjd_kernel<7>, grid, block, 0, s, moments->sum_jump, n_steps, n_chains, stride, esjd_out); break;
+    case 8: hipLaunchKernelGGL(moments_esjd_kernel<8>, grid, block, 0, s, moments->sum_jump, n_steps, n_chains, stride, esjd_out); break;
     }
     return finish_launch();
 }

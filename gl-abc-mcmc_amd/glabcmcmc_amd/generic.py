@@ -78,9 +78,6 @@ class ModelCallbacks:
         self.where = None if self.auto else callback_device
         self.noise_dim = int(getattr(abc_set, "noise_dim", 0)) if hasattr(abc_set, "simulate_from_noise") else 0
 
-    def _to(self, t):
-        return t if self.where == "cuda" else t.cpu()
-
     def _back(self, t, rows):
         t = torch.as_tensor(t)
         return t.detach().to(device=self.device, dtype=torch.float32).reshape(rows, -1).contiguous()
@@ -205,11 +202,9 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     run_.seed, run_.n_steps, run_.global_frequency, run_.batch_size, run_.hist_stride = key, 1, float(global_frequency), N, n
     if ms is not None:
         run_.moments = C.pointer(ms)
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     hist_ptr, hist_row_bytes = (hist.data_ptr(), hist[0].numel() * 4) if hist is not None else (0, 0)
     lp = C.byref(local_desc) if local_desc is not None else None
     gp = C.byref(global_desc) if global_desc is not None else None
-    row0_local = None
 
     keep = {}                                              # tensors whose addresses the current StepIO holds
 

@@ -526,6 +526,11 @@ def primitives():
         out["gf_%s_shape" % tag], out["gf_%s_rate" % tag] = np.array(shape, np.float32), np.array(rate, np.float32)
         out["gf_%s_seed_row0" % tag] = np.array([seed, row0], np.int64)
         out["gf_%s_z" % tag], out["gf_%s_log_p" % tag] = z_ref.numpy(), lp_ref.numpy()
+    # esjd (ESJD.py:2-25) beyond theta_dim 4: continues the esjd_chain_<i> sequence above
+    for i, (T, d) in enumerate(((300, 6), (500, 8), (60, 5)), start=len(chains)):
+        x = np.cumsum((rng.random((T, d)) < 0.3) * rng.standard_normal((T, d)), axis=0).astype(np.float32)
+        out["esjd_chain_%d" % i] = x
+        out["esjd_value_%d" % i] = np.float32(float(resjd.esjd(torch.from_numpy(x))))
     np.savez_compressed(os.path.join(HERE, "primitives.npz"), **out)
     print("primitives: %d arrays" % len(out))
 

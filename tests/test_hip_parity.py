@@ -488,12 +488,12 @@ def test_esjd_kernel(hip, oracle, prim):
     i = 0
     while "esjd_chain_%d" % i in prim:
         x = prim["esjd_chain_%d" % i]
-        if x.shape[1] <= 4:
-            ref = prim["esjd_value_%d" % i]
-            got = esjd(torch.from_numpy(x))
-            assert got.shape == () and got.dtype == np.float32
-            assert abs(got - ref) <= 2e-5 * abs(ref), (i, got, ref)
+        ref = prim["esjd_value_%d" % i]
+        got = esjd(torch.from_numpy(x))
+        assert got.shape == () and got.dtype == np.float32
+        assert abs(got - ref) <= (2e-5 if x.shape[1] <= 4 else 2e-4) * abs(ref), (i, got, ref)
         i += 1
+    assert i >= 9                                          # theta_dim 5, 6 and 8 included
     assert esjd(torch.tensor([[0, 0], [1, 0], [1, 2], [1, 2], [0, 1.0]])) == np.float32(0.75)
 
 
