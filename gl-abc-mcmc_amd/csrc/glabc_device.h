@@ -27,8 +27,10 @@
 // are cached instead of recomputed (pure functions of the state), and x / 1.0f is x.
 #pragma once
 
+#if !defined(__HIPCC_RTC__)          // hiprtc (glabc_rtc.hip) brings the HIP device declarations and the fixed-width types itself
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "../../include/glabc.h"
 #include "../../include/glabc_numerics.h"

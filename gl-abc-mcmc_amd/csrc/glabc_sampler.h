@@ -117,6 +117,7 @@ __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D, YD> a)
     }
 }
 
+#if !defined(__HIPCC_RTC__)       // host-side declarations: not for the run-time compiled form (glabc_rtc.hip)
 // host-side launcher of one theta_dim; defined in glabc_sampler_dim.hip (one TU per D and schedule).
 // lanes = lanes per chain actually compiled for (1, 2 or 4).  Returns a glabc_status.
 // SCHED_ILP objects hold the one-lane-per-chain kernels only (the schedule for launches of at most two waves per SIMD).
@@ -128,5 +129,6 @@ int launch_sampler_dim(int algo, int n_batch, int lanes, const StepArgs<D, YD>& 
 // lanes = 0 (choose) or 8 / 16 / 32 / 64.
 template <int D, int YD>
 int launch_wide(const StepArgs<D, YD>& a, int n_batch, int lanes, hipStream_t stream);
+#endif
 
 }  // namespace glabc

@@ -33,7 +33,9 @@
 #ifndef GLABC_H
 #define GLABC_H
 
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {

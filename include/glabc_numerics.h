@@ -24,7 +24,9 @@
 #ifndef GLABC_NUMERICS_H
 #define GLABC_NUMERICS_H
 
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#endif
 
 #if defined(__HIPCC__)
 #define GLABC_HD static __host__ __device__ __forceinline__
