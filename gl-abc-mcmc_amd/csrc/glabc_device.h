@@ -314,12 +314,26 @@ GLABC_DEV void sort_ascending(float (&v)[N])
     }
 }
 
+// Standard normals one simulation consumes: y_dim for the built-in simulators; a run-time compiled user simulator
+// (glabc_rtc.hip defines GLABC_USER_SIM / GLABC_USER_NOISE_DIM before this header) declares its own count.
+#ifdef GLABC_USER_SIM
+template <int YD> struct NoiseDim { static constexpr int value = GLABC_USER_NOISE_DIM; };
+#else
+template <int YD> struct NoiseDim { static constexpr int value = YD; };
+#endif
+
 // generate_samples for one theta and one simulation.
 //   ABS_GAUSS, examples/Mixture.py:19-23:  y = |theta| + (loc + scale*eps)
 //   GK, examples/GK.py:  y_j = A + B (1 + c tanh(g z_j / 2)) (1 + z_j^2)^k z_j, then sorted (order statistics)
+//   USER (run-time compiled builds only): glabc_user_simulate(theta, eps, y), the caller's C source
 template <int D, int YD>
-GLABC_DEV void model_simulate(const StepArgs<D, YD>& a, const float (&theta)[D], const float (&eps)[YD], float (&y)[YD])
+GLABC_DEV void model_simulate(const StepArgs<D, YD>& a, const float (&theta)[D], const float (&eps)[NoiseDim<YD>::value],
+                              float (&y)[YD])
 {
+#ifdef GLABC_USER_SIM
+    glabc_user_simulate(theta, eps, y);
+    return;
+#else
     if constexpr (YD == D) {
         if (D < 4 || a.sim_kind == GLABC_SIM_ABS_GAUSS) {        // D < 4: the g-and-k shape cannot occur, no run-time test
 #pragma unroll
@@ -342,6 +356,7 @@ GLABC_DEV void model_simulate(const StepArgs<D, YD>& a, const float (&theta)[D],
         }
         sort_ascending<YD>(y);
     }
+#endif
 }
 
 // calculate_log_kernel, Mixture.py:33-45: DiagGaussian(1, 0, log eps).log_prob(||y - y_obs||)
@@ -487,7 +502,8 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
     // one [0,1) draw -- a simulator normal must never share a word with a proposal draw (theta' and y' would not be
     // independent; with odd D and the pair straddling the boundary they were not)
     constexpr int DP = D + (D & 1);
-    constexpr int M = DP + YD;
+    constexpr int ND = NoiseDim<YD>::value;            // simulator normals (= YD for the built-in simulators)
+    constexpr int M = DP + ND;
     constexpr int SPP = (M + 3) / 4;
 
     uint32_t hw[4];
@@ -550,19 +566,19 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
         }
         const bool loc = first && !is_global;
         const bool uni = loc ? l_uni : g_uni;
-        float nrm[2 * ((M + 1) / 2)], e[D], s[YD];
+        float nrm[2 * ((M + 1) / 2)], e[D], s[ND];
 #pragma unroll
         for (int i = 0; 2 * i < M; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
 #pragma unroll
         for (int i = 0; i < D; ++i) e[i] = (!GU && uni) ? glabc_uniform_f32(w[i]) : nrm[i];
 #pragma unroll
-        for (int i = 0; i < YD; ++i) s[i] = nrm[DP + i];
+        for (int i = 0; i < ND; ++i) s[i] = nrm[DP + i];
         if constexpr (TAPE) {                       // the tape holds this candidate's draws in the same order
             const float* tz = a.tape_z + (tape_pos * a.tape_nprop + (j < a.tape_nprop ? j : 0)) * (D + YD);
 #pragma unroll
             for (int i = 0; i < D; ++i) e[i] = tz[i];
 #pragma unroll
-            for (int i = 0; i < YD; ++i) s[i] = tz[D + i];
+            for (int i = 0; i < ND; ++i) s[i] = tz[D + i];
         }
 #pragma unroll
         for (int q = 0; q < D; ++q) {

@@ -504,9 +504,19 @@ static int check_dist(const glabc_dist* g, int dim)
     return GLABC_OK;
 }
 
-static int check_model(const glabc_model* m)
+static int check_model(const glabc_model* m, bool allow_user_sim = false)
 {
     if (!m) return GLABC_ERR_NULL;
+    if (allow_user_sim && m->sim_kind == GLABC_SIM_USER) {            // row-wise callbacks: the simulator is not involved
+        if (m->theta_dim < 1 || m->theta_dim > GLABC_MAX_DIM || m->y_dim < 1 || m->y_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+        int rc0 = check_dist(&m->prior, m->theta_dim);
+        if (rc0) return rc0;
+        if (!std::isfinite(m->kern_log_scale) || !(m->kern_scale > 0.0f) || !std::isfinite(m->kern_scale) || !std::isfinite(m->kern_c0))
+            return GLABC_ERR_ARG;
+        for (int j = 0; j < m->y_dim; ++j)
+            if (!std::isfinite(m->y_obs[j])) return GLABC_ERR_ARG;
+        return GLABC_OK;
+    }
     if (m->sim_kind != GLABC_SIM_ABS_GAUSS && m->sim_kind != GLABC_SIM_GK) return GLABC_ERR_KIND;
     if (m->theta_dim < 1 || m->theta_dim > GLABC_MAX_DIM || m->y_dim < 1 || m->y_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
     int rc = check_dist(&m->prior, m->theta_dim);
@@ -1088,7 +1098,7 @@ __attribute__((visibility("default"))) int glabc_dist_log_prob(const glabc_dist*
 
 static int model_rowwise(const glabc_model* m, const float* in, int64_t n, float* out, void* stream, int op)
 {
-    int rc = check_model(m);
+    int rc = check_model(m, true);
     if (rc) return rc;
     if (!in || !out) return GLABC_ERR_NULL;
     if (n < 0) return GLABC_ERR_ARG;

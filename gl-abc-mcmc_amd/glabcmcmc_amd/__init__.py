@@ -19,7 +19,8 @@ from .AGLMCMC import AGLMCMC
 from .GLMCMC_NFs import GLMCMC_NF
 from .ESJD import esjd
 from .kernel_density import KernelDensity
-from . import _capi, checkpoint, distribution, engine, flows, parallel, streaming
+from .compiled import CompiledModel
+from . import _capi, checkpoint, compiled, distribution, engine, flows, generic, parallel, streaming
 
 __all__ = ["GlobalMCMC", "MCMCRunner", "Uniform", "Gamma", "DiagGaussian", "GaussianMixture", "GLMALA", "GLMCMC",
-           "AGLMCMC", "GLMCMC_NF", "esjd", "KernelDensity", "distribution", "engine"]
+           "AGLMCMC", "GLMCMC_NF", "esjd", "KernelDensity", "distribution", "engine", "CompiledModel"]

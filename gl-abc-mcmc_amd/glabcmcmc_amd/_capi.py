@@ -19,6 +19,7 @@ DIST_GAMMA = 2
 
 SIM_ABS_GAUSS = 0
 SIM_GK = 1
+SIM_USER = 2
 
 FLAG_LOCAL = 1
 DEBUG_EXACT_INDEX = 1          # glabc_run.debug_flags
@@ -237,6 +238,11 @@ ENTRY_POINTS = {
     "glabc_kde_sample": (C.c_int, [_P(Kde), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_kde_train_weights": (C.c_int, [_P(Model), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_init_weights": (C.c_int, [_P(Model), _P(Dist), _P(Chains), C.c_void_p]),
+    "glabc_rtc_compile": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_void_p), C.c_char_p,
+                                    C.c_int64]),
+    "glabc_rtc_steps": (C.c_int, [C.c_void_p, _P(Model), _P(Dist), _P(Dist), _P(Chains), _P(Run), C.c_void_p]),
+    "glabc_rtc_simulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_rtc_release": (None, [C.c_void_p]),
     "glabc_propose": (C.c_int, [C.c_int, _P(Dist), _P(Dist), _P(Chains), _P(Run), _P(StepIO), C.c_void_p]),
     "glabc_propose_redraw": (C.c_int, [_P(Dist), _P(Chains), _P(Run), _P(StepIO), C.c_int32, C.c_void_p, C.c_void_p]),
     "glabc_select": (C.c_int, [C.c_int, _P(Dist), _P(Chains), _P(Run), _P(StepIO), C.c_void_p]),

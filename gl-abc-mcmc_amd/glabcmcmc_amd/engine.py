@@ -132,7 +132,8 @@ class Moments:
 
 
 def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0, seed, global_frequency, batch_size,
-              history=None, moments=None, steps_per_launch=None, lanes_per_chain=0, debug_flags=0, gf_per_chain=None):
+              history=None, moments=None, steps_per_launch=None, lanes_per_chain=0, debug_flags=0, gf_per_chain=None,
+              rtc_program=None):
     """Advance `chains` by n_steps iterations with the C-ABI entry point `entry`
     ('glabc_glmcmc_steps' / 'glabc_globalmcmc_steps'), K iterations per launch.
 
@@ -140,9 +141,17 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
     lanes_per_chain: 0 = let the library choose from the chain count; 1 / 2 / 4 force the
     launch geometry (results are identical for every choice).
     gf_per_chain: None or float32 device tensor [C] replacing global_frequency chain by chain.
+    rtc_program: handle of glabc_rtc_compile -- the launches then go to glabc_rtc_steps (a Model whose simulator was compiled
+    into the kernel at run time, compiled.CompiledModel) with the same arguments.
     """
     lib = _capi.lib()
-    fn = getattr(lib, entry)
+    if rtc_program is not None:
+        entry = "glabc_rtc_steps"
+
+        def fn(*a):
+            return lib.glabc_rtc_steps(rtc_program, *a)
+    else:
+        fn = getattr(lib, entry)
     k_max = int(steps_per_launch or MAX_STEPS_PER_LAUNCH)
     cs = chains.struct()
     ms = moments.struct() if moments is not None else None

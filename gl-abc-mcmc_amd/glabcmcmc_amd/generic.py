@@ -61,6 +61,8 @@ def fused_supported(ABCset, proposals, batch_size, max_batch=None):
         d = try_descriptor(p)
         if d is None or not isinstance(d, _capi.Dist) or d.dim != m.theta_dim:
             return False
+    if m.sim_kind == _capi.SIM_USER:                         # compiled.CompiledModel: register kernels only, compiled per batch size
+        return hasattr(ABCset, "program") and (batch_size is None or 1 <= int(batch_size) <= _capi.MAX_BATCH)
     if m.sim_kind == _capi.SIM_ABS_GAUSS and not 1 <= m.theta_dim <= 4:
         return False                                         # the fused kernels are instantiated for theta_dim 1..4
     return batch_size is None or 1 <= int(batch_size) <= (max_batch or _capi.MAX_BATCH)

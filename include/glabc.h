@@ -78,9 +78,12 @@ typedef struct glabc_dist {
 /* ---- the Model callbacks: glabcmcmc/examples/Mixture.py:5-53 ------------- */
 typedef enum glabc_sim_kind {
     GLABC_SIM_ABS_GAUSS = 0,       /* y = |theta| + noise, noise ~ DiagGaussian   Mixture.py:13-26 */
-    GLABC_SIM_GK = 1               /* g-and-k order statistics (BASELINE config 4; no counterpart in the reference tree --
+    GLABC_SIM_GK = 1,              /* g-and-k order statistics (BASELINE config 4; no counterpart in the reference tree --
                                       the Model is the build's own, glabcmcmc_amd/examples/GK.py): theta = (A, B, g, k),
                                       y = sort_j( A + B (1 + c tanh(g z_j/2)) (1 + z_j^2)^k z_j ), z_j ~ N(0,1), j < y_dim = 8 */
+    GLABC_SIM_USER = 2             /* the caller's simulator, C source compiled into the fused kernel at run time (glabc_rtc_compile):
+                                      y[y_dim] = glabc_user_simulate(theta[theta_dim], eps[noise.dim] standard normals); only
+                                      glabc_rtc_steps and the row-wise Model callbacks accept it */
 } glabc_sim_kind;
 
 typedef struct glabc_model {
@@ -355,6 +358,29 @@ int glabc_propose_redraw(const glabc_dist* local, const glabc_chains* chains, co
  * Theta_Re row; run->moments the streaming sums).  chains->log_w / flags are required for GLABC_ALGO_GLMCMC. */
 int glabc_select(int algo, const glabc_dist* global, const glabc_chains* chains, const glabc_run* run,
                  const glabc_step_io* io, void* stream);
+
+/* ---- user simulators inside the fused kernel (run-time compilation, hiprtc) ----------------------------------------------
+ * The reference's generate_samples is any Python method (examples/Mixture.py:13-26).  Its GPU counterpart is a few lines of C:
+ *
+ *     GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)
+ *     {   // theta[GLABC_THETA_DIM], eps[GLABC_NOISE_DIM] standard normals -> y[GLABC_Y_DIM]
+ *         for (int j = 0; j < GLABC_Y_DIM; ++j) y[j] = fabsf(theta[j]) + 0.2236068f * eps[j];
+ *     }
+ *
+ * glabc_rtc_compile builds the library's own sampler code (Philox slots, proposals, prior, discrepancy ||y - y_obs||, Gaussian
+ * ABC kernel, iSIR / MH decisions, history, sums -- the source of the built-in kernels, embedded in the library) around that
+ * function for one configuration (algorithm, dimensions, batch size) and returns a handle; glabc_rtc_steps is then
+ * glabc_glmcmc_steps / glabc_globalmcmc_steps for a glabc_model with sim_kind = GLABC_SIM_USER (noise.dim = the normals the
+ * simulator consumes).  Written with + - * / fma, sqrtf and the glabc_* functions of glabc_numerics.h the simulator gives
+ * results a CPU build of the same source reproduces bit for bit.  log (may be NULL) receives the compiler's messages. */
+typedef struct glabc_rtc_program glabc_rtc_program;
+int glabc_rtc_compile(const char* simulator_source, int32_t algo, int32_t theta_dim, int32_t y_dim, int32_t noise_dim,
+                      int32_t batch_size, glabc_rtc_program** out, char* log, int64_t log_size);
+int glabc_rtc_steps(const glabc_rtc_program* program, const glabc_model* model, const glabc_dist* local, const glabc_dist* global,
+                    const glabc_chains* chains, const glabc_run* run, void* stream);
+/* generate_samples(theta, 1) of the compiled simulator on n row-major points: theta[n][theta_dim], eps[n][noise_dim] -> y[n][y_dim] */
+int glabc_rtc_simulate(const glabc_rtc_program* program, const float* theta, const float* eps, int64_t n, float* y, void* stream);
+void glabc_rtc_release(glabc_rtc_program* program);
 
 /* generate_samples(theta, 1) of a descriptor Model on n row-major points (Mixture.py:13-26 regime n x 1):
  * theta[n][theta_dim], eps[n][y_dim] standard normals (NULL: drawn from Philox(seed; row0 + r, 0, b), pairs of words)

@@ -273,8 +273,21 @@ static float gk_tanhf(float x)
  *   GLABC_SIM_ABS_GAUSS, Mixture.py:19-23:  y = |theta| + (loc + exp(log_scale)*eps)
  *   GLABC_SIM_GK (the build's own Model, no counterpart in the reference tree; glabcmcmc_amd/examples/GK.py):
  *       y_j = A + B (1 + c tanh(g z_j/2)) (1 + z_j^2)^k z_j,  theta = (A, B, g, k), then sorted ascending */
+/* GLABC_SIM_USER: the caller's simulator (include/glabc.h, glabc_rtc_compile) built by the host compiler from the same
+ * source and registered here by the tests */
+typedef void (*oracle_user_sim_fn)(const float* theta, const float* eps, float* y);
+static oracle_user_sim_fn g_user_sim = NULL;
+ORACLE_API void oracle_set_user_simulator(oracle_user_sim_fn fn) { g_user_sim = fn; }
+
+/* standard normals one simulation consumes: y_dim for the built-in simulators, noise.dim for a user simulator */
+static int model_noise_dim(const glabc_model* m) { return m->sim_kind == GLABC_SIM_USER ? m->noise.dim : m->y_dim; }
+
 static void model_simulate(const glabc_model* m, const float* theta, const float* eps, float* y)
 {
+    if (m->sim_kind == GLABC_SIM_USER) {
+        g_user_sim(theta, eps, y);
+        return;
+    }
     if (m->sim_kind == GLABC_SIM_GK) {
         for (int j = 0; j < m->y_dim; ++j) {
             float z = eps[j];
@@ -330,10 +343,12 @@ static float model_log_kernel(const glabc_model* m, const float* y)
 static int model_check(const glabc_model* m)
 {
     if (!m) return GLABC_ERR_NULL;
-    if (m->sim_kind != GLABC_SIM_ABS_GAUSS && m->sim_kind != GLABC_SIM_GK) return GLABC_ERR_KIND;
+    if (m->sim_kind != GLABC_SIM_ABS_GAUSS && m->sim_kind != GLABC_SIM_GK && m->sim_kind != GLABC_SIM_USER) return GLABC_ERR_KIND;
     if (m->theta_dim < 1 || m->theta_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
     if (m->y_dim < 1 || m->y_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
     if (m->prior.dim != m->theta_dim) return GLABC_ERR_DIM;
+    if (m->sim_kind == GLABC_SIM_USER)
+        return (g_user_sim && m->noise.dim >= 1 && m->noise.dim <= GLABC_MAX_DIM) ? 0 : GLABC_ERR_KIND;
     if (m->sim_kind == GLABC_SIM_GK) return m->theta_dim == 4 ? 0 : GLABC_ERR_DIM;
     if (m->y_dim != m->theta_dim) return GLABC_ERR_DIM;        /* |theta| + noise is elementwise */
     if (m->noise.dim != m->y_dim) return GLABC_ERR_DIM;
@@ -629,7 +644,7 @@ ORACLE_API int oracle_glmcmc_steps(const glabc_model* m, const glabc_dist* local
     int N = run->batch_size;
     if (N < 1 || N > GLABC_MAX_BATCH_WIDE) return GLABC_ERR_ARG;
     if (N > GLABC_MAX_BATCH && run->tape) return GLABC_ERR_ARG;
-    int d = m->theta_dim, yd = m->y_dim;
+    int d = m->theta_dim, yd = m->y_dim, nd = model_noise_dim(m);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < c->n_chains; ++i) {
         chain_state s;
@@ -644,15 +659,15 @@ ORACLE_API int oracle_glmcmc_steps(const glabc_model* m, const glabc_dist* local
             if (run->tape)
                 draws_from_tape(&dr, run->tape, i, t, run->n_steps, N, d, yd);
             else
-                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, N, d, yd, 0);
+                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, N, d, nd, 0);
             const float gf = run->global_frequency_per_chain ? run->global_frequency_per_chain[i] : run->global_frequency;
             if (dr.u_branch < gf) {                                                 /* GLMCMC.py:59 */
                 if (!run->tape && imp->kind == GLABC_DIST_UNIFORM)
-                    draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, N, d, yd, 1);
+                    draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, N, d, nd, 1);
                 s.n_moves += (uint32_t)isir_move(m, imp, N, &s, &dr);
             } else {
                 if (!run->tape && local->kind == GLABC_DIST_UNIFORM)
-                    draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, yd, 1);
+                    draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, nd, 1);
                 if (local_move(m, local, &s, &dr)) {
                     s.flags |= GLABC_FLAG_LOCAL;                                    /* :100 */
                     s.n_moves += 1u;
@@ -694,7 +709,7 @@ ORACLE_API int oracle_globalmcmc_steps(const glabc_model* m, const glabc_dist* l
 {
     int rc = run_check(m, local, glob, c, run);
     if (rc) return rc;
-    int d = m->theta_dim, yd = m->y_dim;
+    int d = m->theta_dim, yd = m->y_dim, nd = model_noise_dim(m);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < c->n_chains; ++i) {
         chain_state s;
@@ -707,12 +722,12 @@ ORACLE_API int oracle_globalmcmc_steps(const glabc_model* m, const glabc_dist* l
             if (run->tape)
                 draws_from_tape(&dr, run->tape, i, t, run->n_steps, 1, d, yd);
             else
-                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, yd, 0);
+                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, nd, 0);
             const float gf = run->global_frequency_per_chain ? run->global_frequency_per_chain[i] : run->global_frequency;
             int is_global = dr.u_branch < gf;                                       /* GlobalMCMC.py:39 */
             const glabc_dist* p = is_global ? glob : local;
             if (!run->tape && p->kind == GLABC_DIST_UNIFORM)
-                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, yd, 1);
+                draws_from_philox(&dr, run->seed, (uint64_t)(c->chain0 + i), run->step0 + (uint32_t)t, 1, d, nd, 1);
             int moved = is_global ? independence_move(m, glob, &s, &dr) : local_move(m, local, &s, &dr);
             s.n_moves += (uint32_t)moved;
             record(run, c, i, t, d, s.theta, prev);                                 /* :53,68 */

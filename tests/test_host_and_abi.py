@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     from glabcmcmc_amd import _capi
     assert os.path.exists(_capi.LIB_PATH), "run `python __graft_entry__.py build` first"
     header = open(os.path.join(ROOT, "include", "glabc.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(glabc_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(glabc_\w+)\s*\(", header, flags=re.M))
     assert declared == set(_capi.ENTRY_POINTS), declared ^ set(_capi.ENTRY_POINTS)
     h = C.CDLL(_capi.LIB_PATH)
     for name in declared:

