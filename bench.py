@@ -225,6 +225,75 @@ def bench_glmcmc_nf(args):
     print(json.dumps(out), flush=True)
 
 
+RTC_MIXTURE = """
+GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)
+{   /* examples/Mixture.py:19-23 written by a user as C: y = |theta| + sqrt(0.05) eps */
+    for (int j = 0; j < GLABC_Y_DIM; ++j) y[j] = fabsf(theta[j]) + 0.2236068f * eps[j];
+}
+"""
+
+
+def bench_rtc(args):
+    """The headline workload (GLMCMC iSIR N=5, gf 0.9, 65 536 chains x --iters iterations per launch, history + sums) with the
+    Model's simulator given as C SOURCE and compiled into the fused kernel at run time (compiled.CompiledModel, glabc_rtc_*):
+    what a user's own simulator costs when it can be stated in C -- against `--workload callback` (the same Model as Python
+    callbacks) and the built-in Mixture_set."""
+    import glabcmcmc_amd as g
+    from glabcmcmc_amd import _capi, engine
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    n, K, N = args.chains, args.iters, args.batch
+    prior = g.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0]))
+    t0 = time.perf_counter()
+    cm = g.CompiledModel(2, 2, RTC_MIXTURE, prior, [1.5, 1.5], EPS)
+    prog = cm.program(_capi.ALGO_GLMCMC, N)
+    compile_s = time.perf_counter() - t0
+    model = cm.descriptor()
+    lp = g.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35]))).descriptor()
+    ip = g.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0])).descriptor()
+    gen = torch.Generator().manual_seed(1234)
+    chains = engine.ChainBatch(torch.zeros(n, 2), (0.05 ** 0.5) * torch.randn(n, 2, generator=gen), dev)
+    hist = torch.empty(K, 2, n, dtype=torch.float32, device=dev)
+    mom = engine.Moments(n, 2, dev)
+    idx = [0]
+
+    def one_step():
+        engine.run_steps("glabc_glmcmc_steps", model, lp, ip, chains, K, 1 + idx[0] * K, 20261003, GF, N, history=hist, moments=mom,
+                         steps_per_launch=K, rtc_program=prog)
+        idx[0] += 1
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        one_step()
+        b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    algo_bytes = 2 * 4 * 7 * n + 2 * 8 * 8 * n + 4 * 2 * n * K
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    esjd = mom.esjd()
+    ok = torch.isfinite(esjd)
+    out = {"metric": "MH accept-steps/sec, user simulator compiled into the fused kernel at run time, 65 536 chains, dim=2",
+           "value": float(n) * K * args.steps / elapsed, "unit": "chain-steps/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "GLMCMC iSIR N=%d gf=0.9, CompiledModel (the Mixture simulator as user C source, hiprtc) eps=0.05 d=2"
+                                  % N, "chains_per_gpu": n, "iters_per_step": K, "batch_size": N},
+           "compile_seconds": compile_s, "esjd_mean": float(esjd[ok].double().mean()),
+           "mean_theta_sq": float(mom.second_moment().diagonal(dim1=1, dim2=2).mean()), "analytic_mean_theta_sq": 2.081014,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "glabc::sampler_kernel<GLMCMC, D=2, N=%d, VAR_GENERIC> (hiprtc)" % N,
+                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                        "note": "VALU-bound like the built-in kernel; the run-time compiled form is the generic variant (IEEE "
+                                "division and square root, no unit-Gaussian shortcuts)"}}
+    print(json.dumps(out), flush=True)
+
+
 def bench_aglmcmc(args):
     """SURVEY.md 8(f) f-4 end to end: AGLMCMC (AGLMCMC.py:44-289; adaptive KDE proposal, annealed threshold) at 65 536 chains
     sharing one density: per iteration KernelDensity.log_prob of the current states + the pool-iSIR / RW-MH kernel, per pool
@@ -436,7 +505,7 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the multi-rank control flow on ONE GPU: every rank uses cuda:0 and the collectives "
                          "run on gloo with CPU copies (numbers are meaningless; RCCL needs one GPU per rank)")
-    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback", "glmcmc_nf", "aglmcmc"],
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback", "glmcmc_nf", "aglmcmc", "rtc"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
@@ -450,6 +519,8 @@ def main():
         return bench_glmcmc_nf(args)
     if args.workload == "aglmcmc":
         return bench_aglmcmc(args)
+    if args.workload == "rtc":
+        return bench_rtc(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -17,6 +17,7 @@
 #include <mutex>
 
 #include "glabc_mala.h"
+#include "glabc_pack.h"
 #include "glabc_sampler.h"
 
 namespace glabc {
@@ -538,23 +539,6 @@ static int check_model(const glabc_model* m, bool allow_user_sim = false)
     return GLABC_OK;
 }
 
-template <int D>
-static DistArgs<D> pack_dist(const glabc_dist* g)
-{
-    DistArgs<D> o;
-    o.kind = g->kind;
-    o.c0 = g->c0;
-    bool unit = g->kind == GLABC_DIST_DIAG_GAUSS;
-    for (int j = 0; j < D; ++j) {
-        o.p0[j] = g->p0[j];
-        o.p1[j] = g->p1[j];
-        o.p2[j] = g->p2[j];
-        unit = unit && (g->p2[j] == 1.0f) && (g->p1[j] == 0.0f);
-    }
-    o.unit_scale = unit ? 1 : 0;
-    return o;
-}
-
 // RN(1/s) if the three-instruction division of model_log_kernel is exact for this divisor, else 0.  The check runs the
 // device's instruction sequence (IEEE mul + two fused multiply-adds) over all 2^23 significands of the dividend and
 // compares with the IEEE quotient (~7 ms, remembered per divisor); powers of two scale every step exactly.
@@ -592,55 +576,8 @@ template <int D, int YD = D>
 static StepArgs<D, YD> pack_args(const glabc_model* m, const glabc_dist* local, const glabc_dist* global,
                                  const glabc_chains* c, const glabc_run* r)
 {
-    StepArgs<D, YD> a;
-    std::memset(&a, 0, sizeof a);
-    a.prior = pack_dist<D>(&m->prior);
-    a.sim_kind = m->sim_kind;
-    a.gk_c = m->gk_c;
-    for (int j = 0; j < YD; ++j) {
-        a.noise_loc[j] = m->noise.p0[j];
-        a.noise_scale[j] = m->noise.p2[j];
-        a.y_obs[j] = m->y_obs[j];
-    }
-    a.y_obs_away = 1;
-    for (int j = 0; j < YD; ++j) a.y_obs_away = a.y_obs_away && (std::fabs(m->y_obs[j]) >= 0x1p-6f);
-    a.kern_log_scale = m->kern_log_scale;
-    a.kern_scale = m->kern_scale;
-    a.kern_c0 = m->kern_c0;
-    a.kern_rinv = (local && YD == D) ? verified_reciprocal(m->kern_scale) : 0.0f;      // sampler launches only
-    a.local = pack_dist<D>(local ? local : global);
-    a.global = pack_dist<D>(global);
-    a.theta = c->theta;
-    a.y = c->y;
-    a.log_w = c->log_w;
-    a.flags = c->flags;
-    a.n_moves = c->n_moves;
-    a.n_chains = c->n_chains;
-    a.chain0 = c->chain0;
-    a.stride = c->stride;
-    if (r) {
-        a.seed_lo = (uint32_t)r->seed;
-        a.seed_hi = (uint32_t)(r->seed >> 32);
-        a.step0 = r->step0;
-        a.n_steps = r->n_steps;
-        a.exact_index = (r->debug_flags & GLABC_DEBUG_EXACT_INDEX) ? 1 : 0;
-        a.gf = r->global_frequency;
-        a.gf_chain = r->global_frequency_per_chain;
-        a.history = r->history;
-        a.hist_stride = r->hist_stride;
-        if (r->moments) {
-            a.sum_theta = r->moments->sum_theta;
-            a.sum_outer = r->moments->sum_outer;
-            a.sum_jump = r->moments->sum_jump;
-        }
-        if (r->tape) {
-            a.tape_u = r->tape->u;
-            a.tape_r = r->tape->r;
-            a.tape_z = r->tape->z;
-            a.tape_nprop = r->tape->n_prop;
-        }
-    }
-    return a;
+    return pack_args_rinv<D, YD>(m, local, global, c, r,
+                                 (local && YD == D) ? verified_reciprocal(m->kern_scale) : 0.0f);      // sampler launches only
 }
 
 static int finish_launch()
