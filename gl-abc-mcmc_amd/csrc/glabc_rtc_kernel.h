@@ -2,7 +2,7 @@
 //
 // The translation unit hiprtc sees is
 //     <fixed-width typedefs>
-//     #define GLABC_RTC_ALGO / _D / _YD / _N             the configuration
+//     #define GLABC_RTC_ALGO / _D / _YD / _N / _L        the configuration (L = lanes per chain, chosen by the host)
 //     #define GLABC_USER_SIM 1, GLABC_USER_NOISE_DIM    make model_simulate call the user's function
 //     #include "glabc_numerics.h"                        so that the user's source can use glabc_expf, glabc_logf, ...
 //     <the user's source: GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)>
@@ -16,7 +16,7 @@
 
 namespace glabc {
 
-template __global__ void sampler_kernel<GLABC_RTC_ALGO, GLABC_RTC_D, GLABC_RTC_YD, GLABC_RTC_N, 1, VAR_GENERIC, 0>(
+template __global__ void sampler_kernel<GLABC_RTC_ALGO, GLABC_RTC_D, GLABC_RTC_YD, GLABC_RTC_N, GLABC_RTC_L, VAR_GENERIC, 0>(
     const StepArgs<GLABC_RTC_D, GLABC_RTC_YD>);
 
 // generate_samples(theta, 1) on rows with the noise supplied (the Model protocol's callback, for y0 and the split-phase path):

@@ -23,6 +23,7 @@ path included.  Use + - * / fmaf sqrtf fabsf and the ``glabc_*`` functions of in
 ``glabc_logf``, ``glabc_sincos2pi`` ...) for results that a CPU build of the same source reproduces bit for bit.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -32,6 +33,10 @@ from .distribution import _fill, _launch_rowwise
 
 
 class SimulatorCompileError(RuntimeError):
+    pass
+
+
+class SimulatorSelfCheckError(RuntimeError):
     pass
 
 
@@ -46,6 +51,7 @@ class CompiledModel:
             raise ValueError("y_obs has %d entries, y_dim is %d" % (self.y_obs.shape[1], self.y_dim))
         self.epsilon = epsilon
         self._programs = {}
+        self._checked = set()
 
     # ---- run-time compiled programs, one per (algorithm, batch size) -------------------------------------------------
     def program(self, algo, batch_size=1):
@@ -58,7 +64,51 @@ class CompiledModel:
             if rc != _capi.OK:
                 raise SimulatorCompileError("glabc_rtc_compile failed (status %d):\n%s" % (rc, log.value.decode(errors="replace")))
             self._programs[key] = handle
+        if key not in self._checked and os.environ.get("GLABC_RTC_SELF_CHECK", "1") != "0":
+            self._checked.add(key)
+            self.self_check(*key)
         return self._programs[key]
+
+    def self_check(self, algo, batch_size=1, n_chains=512, steps=4, seed=20240229):
+        """The freshly compiled kernel against the split-phase path on the same Philox streams: a few iterations of
+        `n_chains` synthetic chains through both (same simulator binary for the rows, library kernels for everything
+        else -- the path tests/test_generic_path.py holds to the CPU checker), compared bit for bit.  Runs once per program
+        (a few ms); GLABC_RTC_SELF_CHECK=0 skips it.  It exists because the run-time compiler has miscompiled this very
+        kernel before: a mismatch raises instead of returning samples from the wrong law."""
+        from .GlobalMCMC import GlobalMCMC
+        from .GLMCMC import GLMCMC
+        dev = engine.require_device(None)
+        g = torch.Generator().manual_seed(seed)
+        d = self.theta_dim
+        pd = self.prior.descriptor()
+        loc = torch.tensor([pd.p0[j] for j in range(d)])
+        scale = torch.tensor([pd.p2[j] for j in range(d)])
+        if pd.kind == _capi.DIST_UNIFORM:                             # p0 = low, p2 = high - low
+            theta0 = loc + scale * torch.rand(n_chains, d, generator=g)
+            imp = distribution.Uniform(d, loc, loc + scale)
+            spread = scale / 4.0
+        else:
+            theta0 = loc + scale * torch.randn(n_chains, d, generator=g)
+            imp = distribution.DiagGaussian(d, loc.clone(), torch.log(scale))
+            spread = scale
+        local = distribution.DiagGaussian(d, torch.zeros(d), torch.log(0.3 * spread))
+        y0 = self.simulate_from_noise(theta0, torch.randn(n_chains, self.noise_dim, generator=g)).cpu()
+        out = []
+        for path, kw in (("fused", {}), ("generic", dict(sentinel_redraw=False, graph=False))):
+            if algo == _capi.ALGO_GLMCMC:
+                r = GLMCMC(self, steps + 1, theta0, y0, local, None, 0.5, imp, batch_size, seed=seed, device=dev, verbose=False,
+                           path=path, **kw)
+            else:
+                r = GlobalMCMC(self, steps + 1, theta0, y0, imp, None, 0.5, local, seed=seed, device=dev, verbose=False, path=path,
+                               **kw)
+            out.append(r[1].contiguous().view(torch.int32))
+        if not torch.equal(out[0], out[1]):
+            bad = int((out[0] != out[1]).any(dim=-1).any(dim=0).sum()) if out[0].dim() == 3 else -1
+            raise SimulatorSelfCheckError(
+                "the run-time compiled kernel (algorithm %d, batch size %d) disagrees with the split-phase path on %d of %d "
+                "chains after %d iterations: refusing to sample with it (use path='generic', and please report the "
+                "simulator source)" % (algo, batch_size, bad, n_chains, steps))
+        return True
 
     def __del__(self):
         try:

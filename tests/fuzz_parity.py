@@ -1,11 +1,12 @@
 """Randomised differential test, gfx950 kernels vs the CPU checker (not collected by pytest; run on the GPU box):
 
-    python tests/fuzz_parity.py [seconds] [seed]
+    python tests/fuzz_parity.py [seconds] [seed] [rtc]
 
 Random theta_dim, batch size (every fourth GLMCMC case beyond 16: the wide kernel, up to 1200 proposals), epsilon (1e-4 .. 10), global_frequency, Gaussian / Uniform proposals with random
 parameters, y_obs (also near zero), lanes per chain, iterations per launch, chain id offsets -- GLMCMC and GlobalMCMC
 histories, final states and streaming sums must agree with the oracle bit for bit; every fourth case is GLMALA
-(random tau, num_grad, float64 state, gradients), every eighth the g-and-k Model.
+(random tau, num_grad, float64 state, gradients), every eighth the g-and-k Model, every sixteenth a random user simulator
+compiled into the kernel at run time (all of them with a third argument `rtc`).
 """
 import ctypes as C
 import os
@@ -209,14 +210,80 @@ def one_case_nf(rng, oracle, k):
     return ok, dict(case=k, algo="nf", couplings=nc, rows=n), 0
 
 
+def random_simulator(rng, d, yd, nd):
+    """C source of a random simulator theta[d], eps[nd] -> y[yd]: each summary a random mix of exp / log / sqrt / fma / abs of
+    random components times random noise components (which eps are read, and how many, varies from case to case)"""
+    lines = []
+    for j in range(yd):
+        a, b, c = (int(rng.integers(0, d)) for _ in range(3))
+        e1, e2 = int(rng.integers(0, nd)), int(rng.integers(0, nd))
+        f = ["fabsf(theta[%d])" % a, "glabc_expf(-0.5f * fabsf(theta[%d]))" % a, "sqrtf(theta[%d] * theta[%d] + 0.25f)" % (a, a),
+             "glabc_logf(1.0f + theta[%d] * theta[%d])" % (a, a), "fmaf(theta[%d], 0.5f, theta[%d])" % (a, b)][int(rng.integers(0, 5))]
+        g = ["%sf * eps[%d]" % (repr(round(float(rng.uniform(0.05, 0.5)), 3)), e1),
+             "%sf * eps[%d] * glabc_expf(0.1f * eps[%d])" % (repr(round(float(rng.uniform(0.05, 0.5)), 3)), e1, e2),
+             "0.2f * eps[%d] + 0.1f * eps[%d] * theta[%d]" % (e1, e2, c)][int(rng.integers(0, 3))]
+        lines.append("    y[%d] = %s + %s;" % (j, f, g))
+    return "GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)\n{\n%s\n}\n" % "\n".join(lines)
+
+
+def one_case_rtc(rng, oracle, k):
+    """A random user simulator compiled into the fused kernel at run time (glabc_rtc_compile) vs the checker calling the same
+    source through gcc; theta_dim / y_dim / noise_dim 1..8, N 1..16."""
+    import glabcmcmc_amd as g_
+    from test_rtc import host_simulator
+    d, yd, nd = int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    algo = "glmcmc" if rng.random() < 0.8 else "globalmcmc"
+    N = int(rng.integers(1, 17)) if algo == "glmcmc" else 1
+    src = random_simulator(rng, d, yd, nd)
+    keep_lib, fn = host_simulator(src, d, yd, nd)
+    oracle.oracle_set_user_simulator(fn)
+    eps = float(np.exp(rng.uniform(np.log(0.05), np.log(5))))
+    gf = float(rng.choice([0.0, 1.0, rng.random()]))
+    lspec, gspec = random_dist(rng, d, True), random_dist(rng, d, False)
+    prior = make_dist(("gauss", [0.0] * d, [float(v) for v in np.exp(rng.normal(0.2, 0.3, d))]))
+    cm = g_.CompiledModel(d, yd, src, prior, [float(v) for v in rng.normal(0.8, 0.3, yd)], eps, noise_dim=nd)
+    model = cm.descriptor()
+    local, glob = make_dist(lspec).descriptor(), make_dist(gspec).descriptor()
+    n, T = int(rng.integers(1, 400)), int(rng.integers(1, 30))
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    theta0 = rng.normal(0, 1, (n, d)).astype(np.float32)
+    y0 = rng.normal(0.8, 0.5, (n, yd)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0)
+    hist = torch.empty(T, d, n, device=dev)       # (no init_weights: the chains start `local`, GLMCMC.py:50, so the first global move computes it)
+    mom = engine.Moments(n, d, dev)
+    a = _capi.ALGO_GLMCMC if algo == "glmcmc" else _capi.ALGO_GLOBALMCMC
+    engine.run_steps(None, model, local, glob, chains, T, 1, seed, gf, N, history=hist, moments=mom, rtc_program=cm.program(a, N))
+    torch.cuda.synchronize()
+    hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
+    hh = np.zeros((T, d, n), np.float32)
+    hm = oracle_lib.HostMoments(n, d)
+    run, keep = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh, moments=hm)
+    cs = hc.struct()
+    if algo == "glmcmc":
+        rc = oracle.oracle_glmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    else:
+        rc = oracle.oracle_globalmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
+    assert rc == 0
+    desc = dict(case=k, algo=algo + "-rtc", d=d, yd=yd, nd=nd, N=N, eps=eps, gf=gf, local=lspec, glob=gspec, n=n, T=T, source=src)
+    ok = np.array_equal(bits(hist.cpu().numpy()), bits(hh)) and np.array_equal(bits(chains.theta.cpu().numpy()), bits(hc.theta)) \
+        and np.array_equal(bits(chains.y.cpu().numpy()), bits(hc.y)) and np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
+    if algo == "glmcmc":
+        ok = ok and np.array_equal(bits(chains.log_w.cpu().numpy()), bits(hc.log_w))
+    del cm
+    return ok, desc, int(hc.n_moves.sum())
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     oracle = oracle_lib.load()
     _capi.lib()
+    RTC_ONLY = len(sys.argv) > 3 and sys.argv[3] == "rtc"
     t0, k, moves, bad = time.time(), 0, 0, []
     while time.time() - t0 < budget:
-        fn = one_case_mala if k % 4 == 3 else one_case_gk if k % 8 == 5 else one_case_nf if k % 32 == 9 else one_case
+        fn = one_case_rtc if (RTC_ONLY or k % 16 == 6) else one_case_mala if k % 4 == 3 else one_case_gk if k % 8 == 5 else \
+            one_case_nf if k % 32 == 9 else one_case
         ok, desc, mv = fn(rng, oracle, k)
         moves += mv
         if not ok:

@@ -162,7 +162,7 @@ def test_hip_compiled_model_walks_the_reference_chains(hip, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo,N", [("glmcmc", 5), ("glmcmc", 12), ("globalmcmc", 1)])
+@pytest.mark.parametrize("algo,N", [("glmcmc", 5), ("glmcmc", 12), ("glmcmc", 13), ("glmcmc", 16), ("globalmcmc", 1)])
 def test_hip_nonlinear_user_simulator_equals_oracle(hip, oracle, algo, N):
     """theta_dim 3, y_dim 2, 4 normals per simulation, exp / log / sqrt / fma in the simulator: kernel == checker (same
     source through hiprtc and gcc), histories, states and streamed sums, bit for bit"""
@@ -206,6 +206,66 @@ def test_hip_nonlinear_user_simulator_equals_oracle(hip, oracle, algo, N):
         keep.glabc_user_simulate_host(theta0[r].ctypes.data_as(C.c_void_p), eps[r].ctypes.data_as(C.c_void_p),
                                       y_host[r].ctypes.data_as(C.c_void_p))
     assert np.array_equal(bits(y_dev[:64]), bits(y_host[:64]))
+
+
+def wide_source(d, yd, nd):
+    return ("GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)\n{\n"
+            "    for (int j = 0; j < %d; ++j)\n"
+            "        y[j] = glabc_expf(-fabsf(theta[j %% %d])) + 0.3f * eps[j %% %d] * glabc_logf(1.0f + theta[(j + 1) %% %d] * theta[(j + 1) %% %d]);\n"
+            "}\n" % (yd, d, nd, d, d))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,yd,nd,N", [(8, 8, 8, 4), (8, 8, 8, 16), (5, 5, 5, 6), (1, 1, 1, 15), (6, 3, 8, 9), (8, 1, 1, 6), (2, 7, 3, 11)])
+def test_hip_user_simulators_of_every_shape_equal_oracle(hip, oracle, d, yd, nd, N):
+    """theta_dim / y_dim / noise_dim up to 8 with N up to 16 (kernels of 190 .. 450 registers per lane): kernel == checker"""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import engine
+    src = wide_source(d, yd, nd)
+    keep, fn = host_simulator(src, d, yd, nd)
+    oracle.oracle_set_user_simulator(fn)
+    cm = g_.CompiledModel(d, yd, src, make_dist(("gauss", [0.0] * d, [1.5] * d)), [0.8] * yd, 0.4, noise_dim=nd)
+    model = cm.descriptor()
+    local = make_dist(("gauss", [0.0] * d, [0.3] * d)).descriptor()
+    glob = make_dist(("gauss", [0.0] * d, [1.2] * d)).descriptor()
+    rng = np.random.default_rng(N)
+    n, T, seed, gf, chain0 = 300, 12, 99 + N, 0.7, 10 ** 9
+    theta0 = rng.standard_normal((n, d)).astype(np.float32)
+    y0 = rng.standard_normal((n, yd)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0)
+    hist = torch.empty(T, d, n, device=dev)
+    engine.run_steps(None, model, local, glob, chains, T, 1, seed, gf, N, history=hist, rtc_program=cm.program(A.ALGO_GLMCMC, N))
+    torch.cuda.synchronize()
+    hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
+    hh = np.zeros((T, d, n), np.float32)
+    run, k2 = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh)
+    cs = hc.struct()
+    assert oracle.oracle_glmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run)) == 0
+    assert np.array_equal(bits(hist.cpu().numpy()), bits(hh)) and hc.n_moves.sum() > n
+    assert np.array_equal(bits(chains.log_w.cpu().numpy()), bits(hc.log_w))
+
+
+@pytest.mark.gpu
+def test_hip_self_check_refuses_a_miscompiled_kernel(hip, monkeypatch):
+    """ROCm 7.2's SLP vectorizer miscompiles the candidate loop of this configuration (one lane per chain, N = 12, a simulator
+    reading eps[0] and eps[2]): the library compiles with -fno-slp-vectorize; switched back on (debug knobs), the program's
+    self-check against the split-phase path must refuse the kernel.  (A toolchain that no longer miscompiles skips.)"""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd.compiled import SimulatorSelfCheckError
+    monkeypatch.setenv("GLABC_RTC_OPTS", "-fslp-vectorize")
+    monkeypatch.setenv("GLABC_RTC_LANES", "1")
+    prior = make_dist(("gauss", [0.0, 0.5, 0.0], [1.5, 1.0, 2.0]))
+    cm = g_.CompiledModel(3, 2, NONLINEAR, prior, [0.9, 0.6], 0.15, noise_dim=4)
+    try:
+        cm.program(A.ALGO_GLMCMC, 12)
+    except SimulatorSelfCheckError as e:
+        assert "disagrees with the split-phase path" in str(e)
+    else:
+        pytest.skip("this toolchain compiles the configuration correctly with the SLP vectorizer on")
+    monkeypatch.delenv("GLABC_RTC_OPTS")
+    cm2 = g_.CompiledModel(3, 2, NONLINEAR, prior, [0.9, 0.6], 0.15, noise_dim=4)
+    assert cm2.program(A.ALGO_GLMCMC, 12)                                  # the library's own options: checked and accepted
 
 
 @pytest.mark.gpu
