@@ -798,15 +798,15 @@ def test_glmala_law_matches_a_large_reference_sample(hip):
     reference as it runs.  tests/golden/glmala_stats.npz holds time averages over 500 iterations of a large
     sample of chains of the UNMODIFIED reference GLMALA run AS IS (tests/golden/make_glmala_stats.py: BASELINE config 3,
     theta0 = 0); the kernel runs the same experiment on 262 144 chains.  Every pooled statistic must agree within 4 combined
-    standard errors, and the posterior moments (E|theta_j|, E theta_j^2) are pinned to better than 2e-3 relative by those
-    errors -- the 1e-3 of north_star within what a CPU-affordable reference sample can resolve."""
+    standard errors; with the reference's 150 016 chains the combined standard error of the posterior moments (E|theta_j|,
+    E theta_j^2) is below north_star's 1e-3 relative (3e-4 and 6e-4), that of ESJD is 1.7e-3."""
     from glabcmcmc_amd import GLMALA, distribution, engine
     from glabcmcmc_amd.examples.Mixture import Mixture_set
     g = load_golden("glmala_stats")
     cfg = eval(str(g["cfg"]), {"__builtins__": {}}, {"dict": dict})
     names = eval(str(g["names"]), {"__builtins__": {}}, {})
     ref_mean, ref_se = dict(zip(names, g["mean"])), dict(zip(names, g["se"]))
-    assert int(g["n_chains"]) >= 30000
+    assert int(g["n_chains"]) >= 150000
     n, T = 262144, cfg["T"]
     dev = torch.device("cuda", 0)
     gen = torch.Generator().manual_seed(99)
@@ -837,7 +837,8 @@ def test_glmala_law_matches_a_large_reference_sample(hip):
         assert abs(m - ref_mean[k]) <= 4.0 * comb, (k, m, ref_mean[k], comb)
     for k in ("mean_abs_0", "mean_abs_1", "mean_sq_0", "mean_sq_1"):
         m, r, comb = report[k]
-        assert comb / abs(r) < 2e-3 and abs(m - r) / abs(r) < 5e-3, (k, report[k])
+        assert comb / abs(r) < 1e-3 and abs(m - r) / abs(r) < 2.5e-3, (k, report[k])
+    assert report["esjd"][2] / report["esjd"][1] < 2e-3
 
 
 # ---------------------------------------------------------------------------------- wide batches (glabc_wide.hip)
