@@ -134,6 +134,73 @@ def bench_nf(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_nf_train(args):
+    """The training step of GLMCMC_NFs.py:112-124 at the pool size of BASELINE configs[4] in batched use: forward_kld over
+    65 536 chains x (N=5 x step_size=20) = 6 553 600 resampled pool rows, 8 couplings; one step = loss + gradient
+    (glabc_nf_grad: inverse pass + one backward launch per coupling + reduction) + Adam (glabc_adam_step).  The same step by
+    torch autograd + torch.optim.Adam on the same device is timed beside it (on a quarter of the rows: its activations
+    need ~1 KiB per row and coupling)."""
+    from glabcmcmc_amd.flows import HipAdam, RealNVP
+    import copy
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    flow = RealNVP(args.couplings)
+    with torch.no_grad():
+        for c in flow.couplings:
+            c.l3.weight.normal_(0, 0.3 / 128 ** 0.5)
+            c.l3.bias.normal_(0, 0.1)
+    flow = flow.cuda()
+    rows = args.chains * NBATCH * 20
+    x = torch.randn(2, rows, device="cuda") * 0.8 + 0.3
+    opt = HipAdam(flow)
+    for _ in range(args.warmup):
+        opt.step(x, chain_major=True)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        opt.gradient(x, chain_major=True)
+        b.record()
+    torch.cuda.synchronize()
+    grad_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        opt.step(x, chain_major=True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # torch autograd + Adam, same model, a quarter of the rows
+    ref = copy.deepcopy(flow)
+    topt = torch.optim.Adam(ref.parameters(), lr=5e-4, weight_decay=1e-5)
+    xr = x[:, :rows // 4].t().contiguous()
+    def torch_step():
+        topt.zero_grad()
+        loss = ref.forward_kld(xr)
+        loss.backward()
+        topt.step()
+        return loss
+    torch_step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        torch_step()
+    torch.cuda.synchronize()
+    torch_rows_per_s = 3 * (rows // 4) / (time.perf_counter() - t1)
+    mfma_flop = 4 * 2.0 * 128 * 128 * args.couplings * rows              # inverse pass + (1), (2), (3) of the backward sweep
+    out = {"metric": "NF training rows/sec (forward_kld + gradient + Adam), RealNVP %d couplings" % args.couplings,
+           "value": rows * args.steps / elapsed, "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "GLMCMC_NF training step: %d couplings x MLP[1,128,128,2], %d pool rows (GLMCMC_NFs.py:112-124)"
+                                  % (args.couplings, rows)},
+           "torch_autograd_rows_per_s": torch_rows_per_s, "speedup_vs_torch_autograd": rows * args.steps / elapsed / torch_rows_per_s,
+           "roofline": {"bound": "mfma", "achieved": mfma_flop / (grad_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": mfma_flop / (grad_ms * 1e-3) / 1e12 / 157.3, "traffic": None,
+                        "kernel": "glabc::nf_kernel<inverse> + glabc::nf_backward_kernel x couplings (v_mfma_f32_32x32x2_f32)",
+                        "kernel_ms": grad_ms}}
+    print(json.dumps(out), flush=True)
+
+
 def bench_kde(args):
     """KernelDensity.log_prob (kernel_density.py:96-128), the dense (points x centres) logsumexp of
     AGLMCMC's adaptive proposal: 524 288 evaluation points against 8192 weighted centres in d = 2 per step."""
@@ -505,12 +572,14 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the multi-rank control flow on ONE GPU: every rank uses cuda:0 and the collectives "
                          "run on gloo with CPU copies (numbers are meaningless; RCCL needs one GPU per rank)")
-    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback", "glmcmc_nf", "aglmcmc", "rtc"],
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback", "glmcmc_nf", "aglmcmc", "rtc", "nf_train"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
     if args.workload == "nf":
         return bench_nf(args)
+    if args.workload == "nf_train":
+        return bench_nf_train(args)
     if args.workload == "kde":
         return bench_kde(args)
     if args.workload == "callback":

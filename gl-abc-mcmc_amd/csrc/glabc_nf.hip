@@ -31,17 +31,10 @@
 
 #include "../../include/glabc.h"
 #include "../../include/glabc_numerics.h"
+#include "glabc_nf_layout.h"
 
 namespace glabc {
 
-constexpr int NF_H = 128;                                     // hidden width, GLMCMC_NFs.py:56
-constexpr int NF_W2_OFF = 0;                                  // layout of one coupling's parameter block (floats)
-constexpr int NF_W1_OFF = NF_H * NF_H;                        //   W2^T [k][i] | W1 | b1 | (b2, W3[0], W3[1], 0)[i] | b3[2] pad[2]
-constexpr int NF_B1_OFF = NF_W1_OFF + NF_H;
-constexpr int NF_V4_OFF = NF_B1_OFF + NF_H;
-constexpr int NF_B3_OFF = NF_V4_OFF + 4 * NF_H;
-constexpr int NF_BLOCK_FLOATS = NF_B3_OFF + 4;                // = GLABC_NF_COUPLING_FLOATS
-static_assert(NF_BLOCK_FLOATS == GLABC_NF_COUPLING_FLOATS, "parameter block layout");
 // The LDS image of a block puts the 3 KiB of vectors FIRST and W2^T behind them: every vector element is then within the
 // 16-bit immediate offset of a ds_read from one base register.  (With the global layout the vectors sit at byte 66 560, past
 // that range, and the compiler kept one address VGPR per accumulator-init / epilogue read -- the spills of round 1.)
@@ -57,8 +50,6 @@ static_assert((L_W2 * 4) % 16 == 0 && L_W2 + NF_H * NF_H == NF_BLOCK_FLOATS, "LD
 constexpr int NF_WAVES = GLABC_NF_WAVES;
 constexpr int NF_MAX_PAIRS = 5;                               // 64-row pairs a wave keeps in registers, at most
 constexpr int NF_CUS = 256;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct NfArgs {
     const float* params;          // [n_couplings][NF_BLOCK_FLOATS]
@@ -244,6 +235,10 @@ __device__ __forceinline__ void nf_row_store(const NfArgs& a, int64_t row, float
         const float e0 = (z0 - a.base_loc[0]) / a.base_scale[0], e1 = (z1 - a.base_loc[1]) / a.base_scale[1];
         const float lp = a.base_c0 - ((a.base_log_scale[0] + 0.5f * (e0 * e0)) + (a.base_log_scale[1] + 0.5f * (e1 * e1)));
         a.log_q[a.idx ? (int64_t)a.idx[row] : row] = lq + lp;
+        if (a.z_out) {                         // glabc_nf_inverse: the base-space point as well (training, glabc_nf_train.hip)
+            a.z_out[row] = z0;
+            a.z_out[a.n_rows + row] = z1;
+        }
     } else {
         a.z_out[row] = z0;
         a.z_out[a.n_rows + row] = z1;
@@ -438,6 +433,16 @@ __attribute__((visibility("default"))) int glabc_nf_log_prob(const glabc_flow* f
     if (!x) return GLABC_ERR_NULL;
     if (n_rows == 0) return GLABC_OK;
     return nf_launch<true>(nf_pack(flow, x, nullptr, log_q, n_rows, 0, 0), (hipStream_t)stream);
+}
+
+__attribute__((visibility("default"))) int glabc_nf_inverse(const glabc_flow* flow, const float* x, int64_t n_rows, float* z_out,
+                                                            float* log_q, void* stream)
+{
+    int rc = nf_check(flow, x, log_q, n_rows);
+    if (rc) return rc;
+    if (!x || !z_out) return GLABC_ERR_NULL;
+    if (n_rows == 0) return GLABC_OK;
+    return nf_launch<true>(nf_pack(flow, x, z_out, log_q, n_rows, 0, 0), (hipStream_t)stream);
 }
 
 __attribute__((visibility("default"))) int glabc_nf_log_prob_indexed(const glabc_flow* flow, const float* theta, int64_t stride,

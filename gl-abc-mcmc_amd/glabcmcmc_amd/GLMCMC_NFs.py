@@ -13,7 +13,8 @@ Same positional signature as the reference function (``base`` is accepted for si
                  and its length stay on the device) and for all chains after an optimizer step -- same values, a few per
                  cent of the work
 * when a pool is used up: at most ``Train_step`` Adam steps on the forward KL of a systematically resampled pool
-  (:112-124, ``resample`` :29-40) -- stock PyTorch autograd on the same device -- then a new pool (:125-140).
+  (:112-124, ``resample`` :29-40) -- ``flows.HipAdam``: hand-written backward on the matrix cores (``glabc_nf_grad``) and
+  ``glabc_adam_step`` -- then a new pool (:125-140).
 
 Batched use (``Initial_theta`` of shape (C, d)): all chains share ONE flow; every chain owns a pool; pools are
 redrawn together as soon as one chain has used its ``step_size`` slices.  With C = 1 this is the reference's schedule.
@@ -25,7 +26,7 @@ import ctypes as C
 import torch
 
 from . import _capi, _host, engine
-from .flows import RealNVP
+from .flows import HipAdam, RealNVP
 
 
 def resample(W, N, u0=None):
@@ -57,7 +58,7 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     if flow is None:
         flow = RealNVP(num_layers, base if isinstance(base, torch.nn.Module) else None)
     flow = flow.to(dev)
-    optimizer = torch.optim.Adam(flow.parameters(), lr=lr, weight_decay=weight_decay)            # :63
+    optimizer = HipAdam(flow, lr=lr, weight_decay=weight_decay)                                  # :63, state on the device
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     hist = _host.allocate_history(num_ite, chains, True)
     kk = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -116,18 +117,13 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
             countdown = int(step_size) - used
             continue
         if num_train < Train_step:                                                                 # :114-124
-            flow.train()
-            optimizer.zero_grad()
             w = pool["w"]
             Train_weight = w / torch.sum(w)
             idx = resample(Train_weight, w.numel())
-            Train_t = pool["theta"].t()[idx].detach().float()
-            loss = flow.forward_kld(Train_t)
-            if not (torch.isnan(loss) | torch.isinf(loss)):
-                loss.backward()
-            optimizer.step()                                                                       # (B11: steps even when backward was skipped)
+            # zero_grad, forward_kld, backward unless the loss is NaN / inf, optimizer.step(): hand-written backward + Adam
+            loss = optimizer.step(pool["theta"][:, idx], chain_major=True)                         # (B11 is moot: see HipAdam)
             num_train += 1
-            losses.append(float(loss.detach()))
+            losses.append(loss)
             blob = flow.packed_params()
             fdesc = flow.descriptor(blob)
             log_prob_all()                                                                         # the flow changed under every chain

@@ -229,6 +229,12 @@ ENTRY_POINTS = {
     "glabc_nf_log_prob": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_nf_log_prob_indexed": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                             C.c_void_p]),
+    "glabc_nf_inverse": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "glabc_nf_grad_workspace": (C.c_int, [C.c_int32, C.c_int64, _P(C.c_int64)]),
+    "glabc_nf_grad": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
+    "glabc_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.c_int32, C.c_void_p]),
     "glabc_pool_weights": (C.c_int, [_P(Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "glabc_glmcmc_nf_step": (C.c_int, [_P(Model), _P(Dist), _P(Pool), _P(Chains), _P(Run), C.c_void_p]),

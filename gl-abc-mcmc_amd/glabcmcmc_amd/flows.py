@@ -4,10 +4,12 @@ The reference builds ``nf.NormalizingFlow(base, [AffineCouplingBlock(MLP([1,128,
 Permute(2, 'swap')] * num_layers)`` from the third-party ``normflows`` package (not vendored, not installable
 offline).  ``RealNVP`` restates that model's published semantics as a plain ``torch.nn.Module``:
 
-* ``forward_kld`` / autograd training run on stock PyTorch ops (GLMCMC_NFs.py:112-124 stays autograd);
 * ``sample(n)`` and ``log_prob(x)`` on a CUDA flow run the hand-written matrix-core kernels behind
   ``glabc_nf_sample`` / ``glabc_nf_log_prob`` (exact-float32 MFMA, include/glabc.h); ``sample_torch`` /
-  ``log_prob_torch`` are the same maps in eager PyTorch (training-time graph, CPU use, cross-checks).
+  ``log_prob_torch`` are the same maps in eager PyTorch (CPU use, cross-checks);
+* the training step of GLMCMC_NFs.py:112-124 on a CUDA flow is ``HipAdam.step(x)``: loss and gradient by the hand-written
+  backward kernels (``glabc_nf_grad``) and ``glabc_adam_step`` on the packed parameters; ``forward_kld`` + autograd on stock
+  PyTorch ops is the cross-check of the tests (and what a CPU flow uses).
 """
 import ctypes as C
 
@@ -103,6 +105,23 @@ class RealNVP(nn.Module):
         assert blob.shape[1] == _capi.NF_COUPLING_FLOATS
         return blob
 
+    @torch.no_grad()
+    def load_packed(self, blob, base=None):
+        """the inverse of packed_params: parameters <- blob [n_couplings][GLABC_NF_COUPLING_FLOATS] (and base = loc0, loc1,
+        log_scale0, log_scale1)"""
+        H = HIDDEN
+        for c, blk in zip(self.couplings, blob):
+            c.l2.weight.copy_(blk[:H * H].view(H, H).t())
+            c.l1.weight.copy_(blk[H * H:H * H + H].view(H, 1))
+            c.l1.bias.copy_(blk[H * H + H:H * H + 2 * H])
+            v4 = blk[H * H + 2 * H:H * H + 6 * H].view(H, 4)
+            c.l2.bias.copy_(v4[:, 0])
+            c.l3.weight.copy_(v4[:, 1:3].t())
+            c.l3.bias.copy_(blk[H * H + 6 * H:H * H + 6 * H + 2])
+        if base is not None:
+            self.q0.loc.copy_(base[0:2].view(1, 2))
+            self.q0.log_scale.copy_(base[2:4].view(1, 2))
+
     def descriptor(self, blob):
         f = _capi.Flow()
         f.n_couplings, f.hidden, f.params = len(self.couplings), HIDDEN, blob.data_ptr()
@@ -150,3 +169,62 @@ class RealNVP(nn.Module):
             _capi.check(_capi.lib().glabc_nf_log_prob(C.byref(f), xx.data_ptr(), xx.shape[1], lq.data_ptr(),
                                                       C.c_void_p(stream)), "glabc_nf_log_prob")
         return lq
+
+
+class HipAdam:
+    """torch.optim.Adam(NF_model.parameters(), lr, weight_decay) of GLMCMC_NFs.py:63 with the step of :112-124 on the device:
+    ``step(x)`` = zero_grad; loss = forward_kld(x); backward unless the loss is NaN / inf; optimizer.step() -- loss and
+    gradient from ``glabc_nf_grad`` (hand-written backward on the matrix cores), the update from ``glabc_adam_step`` on the
+    packed parameter blob; the module's parameters are refreshed from the blob afterwards.  (With a NaN / inf loss the
+    reference's ``optimizer.step()`` finds no gradients and changes nothing; neither does this.)"""
+
+    def __init__(self, flow, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5):
+        dev = flow._device()
+        if dev.type != "cuda":
+            raise RuntimeError("HipAdam drives the HIP training kernels: the flow must be on a cuda (HIP) device")
+        self.flow, self.lr, self.betas, self.eps, self.weight_decay = flow, lr, betas, eps, weight_decay
+        self.blob = flow.packed_params()
+        self.base = torch.cat([flow.q0.loc.detach().reshape(-1), flow.q0.log_scale.detach().reshape(-1)]).float().contiguous()
+        self.state = [torch.zeros_like(t) for t in (self.blob, self.blob, self.base, self.base)]    # exp_avg, exp_avg_sq x 2
+        self.grad_blob, self.grad_base = torch.zeros_like(self.blob), torch.zeros_like(self.base)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.steps = 0
+        self._ws = None
+
+    def gradient(self, x, chain_major=False):
+        """x (n, 2) -- or (2, n) with chain_major -- -> (loss tensor, grad blob, grad base) on the device; nothing is updated"""
+        flow, dev = self.flow, self.flow._device()
+        xx = x.detach().to(dev, torch.float32)
+        xx = (xx if chain_major else xx.reshape(-1, 2).t()).contiguous()
+        n = xx.shape[1]
+        f = flow.descriptor(self.blob)
+        f.base_loc[0], f.base_loc[1] = float(self.base[0]), float(self.base[1])
+        f.base_log_scale[0], f.base_log_scale[1] = float(self.base[2]), float(self.base[3])
+        sc = torch.exp(self.base[2:4]).cpu()
+        f.base_scale[0], f.base_scale[1] = float(sc[0]), float(sc[1])
+        need = C.c_int64()
+        _capi.check(_capi.lib().glabc_nf_grad_workspace(f.n_couplings, n, C.byref(need)), "glabc_nf_grad_workspace")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _capi.check(_capi.lib().glabc_nf_grad(C.byref(f), xx.data_ptr(), n, self._ws.data_ptr(), self._ws.numel(),
+                                                  self.grad_blob.data_ptr(), self.grad_base.data_ptr(), self.loss.data_ptr(),
+                                                  C.c_void_p(stream)), "glabc_nf_grad")
+        return self.loss, self.grad_blob, self.grad_base
+
+    def step(self, x, chain_major=False):
+        loss, gb, gq = self.gradient(x, chain_major)
+        value = float(loss)                                      # one synchronisation per training step (GLMCMC_NFs.py:121)
+        if value != value or value in (float("inf"), float("-inf")):
+            return value
+        self.steps += 1
+        dev = self.flow._device()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            for p, g, m, v in ((self.blob, gb, self.state[0], self.state[1]), (self.base, gq, self.state[2], self.state[3])):
+                _capi.check(_capi.lib().glabc_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), self.lr,
+                                                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps,
+                                                        C.c_void_p(stream)), "glabc_adam_step")
+        self.flow.load_packed(self.blob, self.base)
+        return value

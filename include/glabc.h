@@ -250,6 +250,27 @@ int glabc_nf_log_prob(const glabc_flow* flow, const float* x, int64_t n_rows, fl
 int glabc_nf_log_prob_indexed(const glabc_flow* flow, const float* theta, int64_t stride, const int32_t* idx,
                               const int32_t* n_dev, int64_t max_rows, float* log_q, void* stream);
 
+/* NF_model.log_prob(x) AND the base-space point it is evaluated at: z_out[2][n] = x pulled back through every coupling. */
+int glabc_nf_inverse(const glabc_flow* flow, const float* x, int64_t n_rows, float* z_out, float* log_q, void* stream);
+
+/* ---- the training step of GLMCMC_NFs.py:63,112-124 -----------------------------------------------------------------------
+ * loss = NF_model.forward_kld(x) = -mean(NF_model.log_prob(x)) over x[2][n_rows] and its gradient with respect to every
+ * parameter, differentiated by hand (the reference lets autograd do it, GLMCMC_NFs.py:120-122): grad_params has the layout
+ * of flow->params ([n_couplings][GLABC_NF_COUPLING_FLOATS], padding entries 0), grad_base = d/d(loc0, loc1, log_scale0,
+ * log_scale1) of the base distribution, *loss is a device scalar.  workspace: device memory of at least
+ * glabc_nf_grad_workspace bytes, contents undefined afterwards.  Floating-point parity (sums over rows run on the matrix
+ * cores in float32, reduced over workgroups in a fixed order): reproducible to the bit from run to run, within 2e-4 of each
+ * tensor's largest entry of the exact gradient (tests/test_nf_train.py). */
+int glabc_nf_grad_workspace(int32_t n_couplings, int64_t n_rows, int64_t* bytes);
+int glabc_nf_grad(const glabc_flow* flow, const float* x, int64_t n_rows, void* workspace, int64_t workspace_bytes,
+                  float* grad_params, float* grad_base, float* loss, void* stream);
+
+/* torch.optim.Adam.step() (GLMCMC_NFs.py:63,123: lr 5e-4, weight_decay 1e-5 added to the gradient, no amsgrad) on `count`
+ * float32 values, step = 1, 2, ...: exp_avg <- lerp(exp_avg, g, 1 - beta1); exp_avg_sq <- beta2 exp_avg_sq + (1 - beta2) g g;
+ * p <- p - lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps). */
+int glabc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, int32_t step, void* stream);
+
 /* ---- GLMCMC_NF (GLMCMC_NFs.py:43-186): iSIR against a pool of flow proposals -----------------------------
  * A pool holds P = batch_size*step_size proposals per chain, row r = p*n_chains + c (slice kk of chain c =
  * rows p in [kk*batch_size, (kk+1)*batch_size)), arrays chain-major [dim][P*n_chains].

@@ -1213,6 +1213,144 @@ ORACLE_API int oracle_nf_log_prob(const glabc_flow* f, const float* x, int64_t n
 }
 
 
+/* ---- the training step of GLMCMC_NFs.py:63,112-124: loss = forward_kld(x) = -mean(log_prob(x)), its gradient, Adam --------
+ * The reference differentiates with autograd; this is the same derivative written out (chain rule through
+ * base.log_prob and, coupling by coupling, through z1' = (z1 - shift(z0)) exp(-log_s(z0)), log_q -= log_s with the
+ * MLP 1 -> 128 -> 128 -> 2, ReLU'(x) = [x > 0] as torch has it), evaluated in DOUBLE from the float32 parameters: the
+ * exact gradient up to 1e-15, against which the float32 kernels are held with a tolerance (tests/test_nf_train.py; this
+ * function itself is checked against torch autograd in float64). grad_params: block layout, doubles -> float at the end. */
+ORACLE_API int oracle_nf_grad(const glabc_flow* f, const float* x, int64_t n, float* grad_params, float* grad_base, float* loss)
+{
+    if (!f || !f->params || !x || !grad_params || !grad_base || !loss) return GLABC_ERR_NULL;
+    if (f->hidden != NF_H || f->n_couplings < 1 || n < 1) return GLABC_ERR_ARG;
+    const int nc = f->n_couplings;
+    const int64_t total = (int64_t)nc * GLABC_NF_COUPLING_FLOATS;
+    double* acc = (double*)calloc((size_t)total + 5, sizeof(double));
+    if (!acc) return GLABC_ERR_ARG;
+    const double gl = -1.0 / (double)n;
+    int failed = 0;
+#pragma omp parallel
+    {
+        double* mine = (double*)calloc((size_t)total + 5, sizeof(double));
+        double* st = (double*)malloc(sizeof(double) * 2 * (size_t)(nc + 1));
+        if (!mine || !st) {
+#pragma omp atomic write
+            failed = 1;
+        } else {
+#pragma omp for schedule(static)
+            for (int64_t r = 0; r < n; ++r) {
+                /* down: x -> base space, remembering the state in front of every coupling */
+                double z0 = x[r], z1 = x[n + r], lq = 0.0;
+                for (int c = nc - 1; c >= 0; --c) {
+                    const float* blk = f->params + (int64_t)c * GLABC_NF_COUPLING_FLOATS;
+                    st[2 * c] = z0;
+                    st[2 * c + 1] = z1;
+                    const double t0 = z1, t1 = z0;
+                    double h1[NF_H], sh = blk[NF_B3_OFF], ls = blk[NF_B3_OFF + 1];
+                    for (int k = 0; k < NF_H; ++k) h1[k] = fmax((double)blk[NF_W1_OFF + k] * t0 + (double)blk[NF_B1_OFF + k], 0.0);
+                    for (int i = 0; i < NF_H; ++i) {
+                        double a2 = blk[NF_V4_OFF + 4 * i];
+                        for (int k = 0; k < NF_H; ++k) a2 += (double)blk[k * NF_H + i] * h1[k];
+                        const double h2 = fmax(a2, 0.0);
+                        sh += (double)blk[NF_V4_OFF + 4 * i + 1] * h2;
+                        ls += (double)blk[NF_V4_OFF + 4 * i + 2] * h2;
+                    }
+                    z0 = t0;
+                    z1 = (t1 - sh) * exp(-ls);
+                    lq -= ls;
+                }
+                const double e0 = (z0 - f->base_loc[0]) / f->base_scale[0], e1 = (z1 - f->base_loc[1]) / f->base_scale[1];
+                lq += (double)f->base_c0 - ((f->base_log_scale[0] + 0.5 * e0 * e0) + (f->base_log_scale[1] + 0.5 * e1 * e1));
+                mine[total] += lq;
+                mine[total + 1] += gl * (e0 / f->base_scale[0]);
+                mine[total + 2] += gl * (e1 / f->base_scale[1]);
+                mine[total + 3] += gl * (e0 * e0 - 1.0);
+                mine[total + 4] += gl * (e1 * e1 - 1.0);
+                double g0 = gl * (-(e0 / f->base_scale[0])), g1 = gl * (-(e1 / f->base_scale[1]));   /* dL/d(z0, z1) */
+                /* back up: coupling 0 was applied last */
+                for (int c = 0; c < nc; ++c) {
+                    const float* blk = f->params + (int64_t)c * GLABC_NF_COUPLING_FLOATS;
+                    double* gb = mine + (int64_t)c * GLABC_NF_COUPLING_FLOATS;
+                    const double in0 = st[2 * c], in1 = st[2 * c + 1];      /* state in front: conditioner input = in1 */
+                    const double t0 = in1;
+                    double h1[NF_H], a2[NF_H], sh = blk[NF_B3_OFF], ls = blk[NF_B3_OFF + 1];
+                    for (int k = 0; k < NF_H; ++k) h1[k] = fmax((double)blk[NF_W1_OFF + k] * t0 + (double)blk[NF_B1_OFF + k], 0.0);
+                    for (int i = 0; i < NF_H; ++i) {
+                        double s2 = blk[NF_V4_OFF + 4 * i];
+                        for (int k = 0; k < NF_H; ++k) s2 += (double)blk[k * NF_H + i] * h1[k];
+                        a2[i] = s2;
+                        const double h2 = fmax(s2, 0.0);
+                        sh += (double)blk[NF_V4_OFF + 4 * i + 1] * h2;
+                        ls += (double)blk[NF_V4_OFF + 4 * i + 2] * h2;
+                    }
+                    const double z1p = (in0 - sh) * exp(-ls);               /* output (g0 <-> conditioner, g1 <-> z1p) */
+                    const double dz1 = g1 * exp(-ls), dsh = -dz1, dls = -(g1 * z1p) - gl;
+                    gb[NF_B3_OFF] += dsh;
+                    gb[NF_B3_OFF + 1] += dls;
+                    double dh1[NF_H];
+                    for (int k = 0; k < NF_H; ++k) dh1[k] = 0.0;
+                    for (int i = 0; i < NF_H; ++i) {
+                        const double h2 = fmax(a2[i], 0.0);
+                        gb[NF_V4_OFF + 4 * i + 1] += dsh * h2;
+                        gb[NF_V4_OFF + 4 * i + 2] += dls * h2;
+                        if (!(a2[i] > 0.0)) continue;
+                        const double da2 = (double)blk[NF_V4_OFF + 4 * i + 1] * dsh + (double)blk[NF_V4_OFF + 4 * i + 2] * dls;
+                        gb[NF_V4_OFF + 4 * i] += da2;
+                        for (int k = 0; k < NF_H; ++k) {
+                            gb[k * NF_H + i] += da2 * h1[k];
+                            dh1[k] += (double)blk[k * NF_H + i] * da2;
+                        }
+                    }
+                    double dt0 = g0;
+                    for (int k = 0; k < NF_H; ++k) {
+                        if (!(h1[k] > 0.0)) continue;
+                        gb[NF_W1_OFF + k] += dh1[k] * t0;
+                        gb[NF_B1_OFF + k] += dh1[k];
+                        dt0 += (double)blk[NF_W1_OFF + k] * dh1[k];
+                    }
+                    g0 = dz1;                                               /* dL/d(in0, in1) */
+                    g1 = dt0;
+                }
+            }
+#pragma omp critical
+            for (int64_t j = 0; j < total + 5; ++j) acc[j] += mine[j];
+        }
+        free(mine);
+        free(st);
+    }
+    if (!failed) {
+        for (int64_t j = 0; j < total; ++j) grad_params[j] = (float)acc[j];
+        *loss = (float)(-acc[total] / (double)n);
+        for (int j = 0; j < 4; ++j) grad_base[j] = (float)acc[total + 1 + j];
+    }
+    free(acc);
+    return failed ? GLABC_ERR_ARG : 0;
+}
+
+/* torch.optim.Adam.step() element by element, the operation order of glabc_adam_step (bit for bit) */
+ORACLE_API int oracle_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                                double eps, double weight_decay, int32_t step)
+{
+    if (!p || !g || !m || !v) return GLABC_ERR_NULL;
+    if (n < 0 || step < 1) return GLABC_ERR_ARG;
+    const float b1 = (float)beta1, omb1 = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2), e = (float)eps,
+                wd = (float)weight_decay, step_size = (float)(lr / (1.0 - pow(beta1, (double)step))),
+                bias2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    (void)b1;
+    for (int64_t j = 0; j < n; ++j) {
+        const float pj = p[j];
+        const float gj = wd != 0.0f ? g[j] + wd * pj : g[j];
+        const float mj = m[j] + (gj - m[j]) * omb1;
+        const float vj = v[j] * b2 + omb2 * (gj * gj);
+        const float denom = sqrtf(vj) / bias2_sqrt + e;
+        m[j] = mj;
+        v[j] = vj;
+        p[j] = pj - step_size * (mj / denom);
+    }
+    return 0;
+}
+
+
 /* ---- GLMCMC_NF pool weights and one iteration against the pool (GLMCMC_NFs.py:73-111,141-152) ---- */
 ORACLE_API int oracle_pool_weights(const glabc_model* m, const float* theta, const float* log_q, int64_t n, uint64_t seed,
                                    int64_t row_id0, float* x_out, float* w_out)

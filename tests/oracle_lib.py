@@ -38,6 +38,9 @@ _SIG = {
     "oracle_log_v": (None, [C.c_void_p, C.c_int64, C.c_void_p]),
     "oracle_nf_sample": (C.c_int, [_P(A.Flow), C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "oracle_nf_log_prob": (C.c_int, [_P(A.Flow), C.c_void_p, C.c_int64, C.c_void_p]),
+    "oracle_nf_grad": (C.c_int, [_P(A.Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "oracle_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, C.c_double, C.c_int32]),
     "oracle_pool_weights": (C.c_int, [_P(A.Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_void_p,
                                       C.c_void_p]),
     "oracle_glmcmc_nf_step": (C.c_int, [_P(A.Model), _P(A.Dist), _P(A.Pool), _P(A.Chains), _P(A.Run)]),
