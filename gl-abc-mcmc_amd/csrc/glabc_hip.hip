@@ -674,10 +674,19 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
         rc = ilp ? launch_sampler_dim<d, d, SCHED_ILP>(algo, r->batch_size, lanes, pack_args<d>(m, local, global, c, r), s) \
                  : launch_sampler_dim<d, d, SCHED_DEFAULT>(algo, r->batch_size, lanes, pack_args<d>(m, local, global, c, r), s); \
         break;
+        // theta_dim 5..8: default-schedule objects only; a lane keeps (2 theta_dim + 4) registers per candidate, so the
+        // candidates are dealt to 2 / 4 lanes as soon as there are that many (the arrays would leave the registers otherwise)
+#define GLABC_HI_CASE(d)                                                                                               \
+    case d: {                                                                                                         \
+        const int hl = (algo != ALGO_GLMCMC || r->tape) ? 1 : r->lanes_per_chain ? lanes : (r->batch_size >= 3 ? 4 : r->batch_size); \
+        rc = launch_sampler_dim<d, d, SCHED_DEFAULT>(algo, r->batch_size, hl, pack_args<d>(m, local, global, c, r), s); \
+    } break;
         switch (m->theta_dim) {
             GLABC_DIM_CASE(1) GLABC_DIM_CASE(2) GLABC_DIM_CASE(3) GLABC_DIM_CASE(4)
+            GLABC_HI_CASE(5) GLABC_HI_CASE(6) GLABC_HI_CASE(7) GLABC_HI_CASE(8)
         default: return GLABC_ERR_DIM;
         }
+#undef GLABC_HI_CASE
 #undef GLABC_DIM_CASE
     }
     if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
@@ -1010,6 +1019,10 @@ __attribute__((visibility("default"))) int glabc_init_weights(const glabc_model*
     case 2: hipLaunchKernelGGL((init_weights_kernel<2, 2>), grid, block, 0, s, pack_args<2>(model, nullptr, importance, c, nullptr)); break;
     case 3: hipLaunchKernelGGL((init_weights_kernel<3, 3>), grid, block, 0, s, pack_args<3>(model, nullptr, importance, c, nullptr)); break;
     case 4: hipLaunchKernelGGL((init_weights_kernel<4, 4>), grid, block, 0, s, pack_args<4>(model, nullptr, importance, c, nullptr)); break;
+    case 5: hipLaunchKernelGGL((init_weights_kernel<5, 5>), grid, block, 0, s, pack_args<5>(model, nullptr, importance, c, nullptr)); break;
+    case 6: hipLaunchKernelGGL((init_weights_kernel<6, 6>), grid, block, 0, s, pack_args<6>(model, nullptr, importance, c, nullptr)); break;
+    case 7: hipLaunchKernelGGL((init_weights_kernel<7, 7>), grid, block, 0, s, pack_args<7>(model, nullptr, importance, c, nullptr)); break;
+    case 8: hipLaunchKernelGGL((init_weights_kernel<8, 8>), grid, block, 0, s, pack_args<8>(model, nullptr, importance, c, nullptr)); break;
     default: return GLABC_ERR_DIM;
     }
     return finish_launch();

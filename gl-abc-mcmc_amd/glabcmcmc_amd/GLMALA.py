@@ -23,7 +23,7 @@ def GLMALA(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad,
         raise ValueError("GLMALA needs Importance_Proposal and batch_size (GLMALA.py:155,158)")
     if path not in ("auto", "fused", "generic"):
         raise ValueError("path must be 'auto', 'fused' or 'generic'")
-    fused_ok = generic.fused_supported(ABCset, (Importance_Proposal,), batch_size) and \
+    fused_ok = generic.fused_supported(ABCset, (Importance_Proposal,), batch_size, max_dim=4) and \
         engine.model_descriptor(ABCset).sim_kind == _capi.SIM_ABS_GAUSS
     if path == "generic" or (path == "auto" and not fused_ok):
         # a Model given as callbacks (generic.py): iSIR through glabc_propose / glabc_select, the MALA move's gradient

@@ -52,7 +52,7 @@ def dist_descriptor(obj, dim):
     return d
 
 
-def fused_supported(ABCset, proposals, batch_size, max_batch=None):
+def fused_supported(ABCset, proposals, batch_size, max_batch=None, max_dim=8):
     """Can the fused kernels (glabc_glmcmc_steps / glabc_globalmcmc_steps / glabc_glmala_steps) run this configuration?"""
     m = try_descriptor(ABCset)
     if m is None or not isinstance(m, _capi.Model):
@@ -63,8 +63,11 @@ def fused_supported(ABCset, proposals, batch_size, max_batch=None):
             return False
     if m.sim_kind == _capi.SIM_USER:                         # compiled.CompiledModel: register kernels only, compiled per batch size
         return hasattr(ABCset, "program") and (batch_size is None or 1 <= int(batch_size) <= _capi.MAX_BATCH)
-    if m.sim_kind == _capi.SIM_ABS_GAUSS and not 1 <= m.theta_dim <= 4:
-        return False                                         # the fused kernels are instantiated for theta_dim 1..4
+    if m.sim_kind == _capi.SIM_ABS_GAUSS:                    # instantiated for theta_dim 1..8 (GLMALA and batch sizes > 16: 1..4)
+        if not 1 <= m.theta_dim <= max_dim:
+            return False
+        if m.theta_dim > 4 and batch_size is not None and int(batch_size) > _capi.MAX_BATCH:
+            return False
     return batch_size is None or 1 <= int(batch_size) <= (max_batch or _capi.MAX_BATCH)
 
 

@@ -35,10 +35,10 @@ def random_dist(rng, d, local):
 
 
 def one_case(rng, oracle, k):
-    d = int(rng.integers(1, 5))
+    d = int(rng.integers(1, 9))                                          # 5 .. 8: the default-schedule objects
     algo = "glmcmc" if rng.random() < 0.7 else "globalmcmc"
     N = int(rng.integers(1, 17)) if algo == "glmcmc" else 1
-    wide = algo == "glmcmc" and rng.random() < 0.25                      # glabc_wide.hip: lane groups share a chain's proposals
+    wide = d <= 4 and algo == "glmcmc" and rng.random() < 0.25           # glabc_wide.hip: lane groups share a chain's proposals
     if wide:
         N = int(rng.choice([17, 31, 32, 33, 64, 65, int(rng.integers(17, 300)), int(rng.integers(300, 1200))]))
     eps = float(np.exp(rng.uniform(np.log(1e-4), np.log(10))))

@@ -225,9 +225,9 @@ def test_lanes_per_chain_is_only_geometry(hip, oracle, N, lanes):
     assert hc.n_moves.sum() > 0
 
 
-@pytest.mark.parametrize("d", [1, 3, 4])
-def test_other_dimensions(hip, oracle, d):
-    """theta_dim 1, 3, 4 (the Model is |theta| + noise in any dimension)."""
+@pytest.mark.parametrize("d,N", [(1, 5), (3, 5), (4, 5), (5, 5), (6, 3), (7, 16), (8, 5), (8, 16), (5, 1), (8, 2)])
+def test_other_dimensions(hip, oracle, d, N):
+    """theta_dim 1 .. 8 (the Model is |theta| + noise in any dimension; 5 .. 8 are the default-schedule objects)."""
     from glabcmcmc_amd import _capi as A
     from glabcmcmc_amd import distribution
     prior = distribution.DiagGaussian(d, torch.zeros(d), torch.zeros(d)).descriptor()
@@ -242,10 +242,12 @@ def test_other_dimensions(hip, oracle, d):
     local = make_dist(("gauss", [0.0] * d, [0.35] * d)).descriptor()
     glob = make_dist(("gauss", [0.1 * j for j in range(d)], [1.0 + 0.1 * j for j in range(d)])).descriptor()
     rng = np.random.default_rng(d)
-    n, T, N = 1030, 150, 5
+    n, T = 1030, 150 if d <= 4 else 60
     theta0 = rng.standard_normal((n, d)).astype(np.float32)
     y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
-    for algo, lanes in (("glmcmc", 1), ("glmcmc", 2), ("glmcmc", 4), ("globalmcmc", 0)):
+    for algo, lanes in (("glmcmc", 0), ("glmcmc", 1), ("glmcmc", 2), ("glmcmc", 4), ("globalmcmc", 0)):
+        if (lanes == 2 and N < 2) or (lanes == 4 and N < 3):
+            continue
         hist, chains, _ = hip_run(algo, model, local, glob, theta0, y0, T, 99 + d, 0.6, N, lanes=lanes)
         hh, hc, _ = oracle_run(oracle, algo, model, local, glob, theta0, y0, T, 99 + d, 0.6, N)
         assert np.array_equal(bits(hist), bits(hh))
