@@ -75,9 +75,17 @@ def cpu_baseline(seconds_target=12.0):
     n = 16384
     T = int(min(max(50, rate * seconds_target / n), 40000))
     rate = run(n, T)
-    return {"value": rate, "unit": "chain-steps/s", "cores": cores, "kind": "port",
-            "sample": "oracle/glabc_oracle.c (C port of GLMCMC.py:58-104), OpenMP over %d threads, %d chains x %d "
-                      "iterations of the bench workload" % (cores, n, T)}
+    out = {"value": rate, "unit": "chain-steps/s", "cores": cores, "kind": "port",
+           "sample": "oracle/glabc_oracle.c (C port of GLMCMC.py:58-104), OpenMP over %d threads, %d chains x %d "
+                     "iterations of the bench workload" % (cores, n, T)}
+    # the reference's own way of running -- one chain, one ATen operation at a time -- restated in oracle/aten_loop.py
+    # (pinned to the reference's tapes bit for bit, tests/test_oracle_golden.py); ~3 s on one core of this host
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
+    import aten_loop
+    out["reference_like"] = {"value": aten_loop.steps_per_second(3.0), "unit": "chain-steps/s", "cores": 1, "kind": "port",
+                             "sample": "oracle/aten_loop.py: one chain, the reference's ATen operation sequence "
+                                       "(GLMCMC.py:58-104, N = 5, gf 0.9), torch on one thread, ~3 s"}
+    return out
 
 
 def bench_nf(args):

@@ -287,3 +287,33 @@ def test_gamma_forward(oracle, prim, tag):
     assert np.array_equal(z.view(np.uint64), z_ref.view(np.uint64))
     assert (z > 0).all() and np.isfinite(lp_ref).all()
     assert np.max(np.abs(lp - lp_ref) / np.maximum(1, np.abs(lp_ref))) < 1e-12
+
+
+# ------------------------------------------------------------------ the ATen-level restatement (oracle/aten_loop.py)
+@pytest.mark.parametrize("name", ["glmcmc_tape_small", "globalmcmc_tape_small"])
+def test_aten_restatement_replays_the_reference_tapes(name):
+    """oracle/aten_loop.py (one chain, the reference's ATen operation sequence: what bench.py times as the reference-like
+    CPU baseline) fed with the stored tapes gives the chains the reference's own loops produced, bit for bit.
+    (The host constants log(sqrt(0.05)), exp(log eps) ... are recomputed by torch as in the reference: the comparison is
+    exact on the machine type that generated the fixture, i.e. in the build container, where the CPU suite runs.)"""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import aten_loop
+    g = load_golden(name)
+    cfg = g["cfg"]
+    consts_here = torch.exp(torch.log(torch.tensor([0.05, 0.05]).sqrt())).numpy()
+    if not np.array_equal(bits(consts_here), bits(g["c_noise_scale"])):
+        pytest.skip("this host's torch rounds exp(log(sqrt(0.05))) differently from the machine that wrote the fixture")
+    model = aten_loop.Mixture(cfg["epsilon"])
+    local, glob = aten_loop.make_distribution(cfg["local"]), aten_loop.make_distribution(cfg["global"])
+    T = cfg["T"]
+    for c in range(g["theta0"].shape[0]):
+        draws = aten_loop.TapeDraws(g["tape_u"][c], g["tape_r"][c], g["tape_z"][c], 2)
+        th0, y0 = torch.from_numpy(g["theta0"][c].copy()), torch.from_numpy(g["y0"][c].copy())
+        if str(g["algo"]) == "glmcmc":
+            out = aten_loop.glmcmc(model, T, th0, y0, local, glob, cfg["gf"], cfg["N"], draws)
+        else:
+            out = aten_loop.globalmcmc(model, T, th0, y0, glob, local, cfg["gf"], draws)
+        assert np.array_equal(bits(out.numpy()), bits(g["chains"][:, c, :])), "chain %d" % c
