@@ -103,13 +103,22 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
     const float b30 = lds[B_B3], b31 = lds[B_B3 + 1];
 
     const int64_t wg_row0 = (int64_t)blockIdx.x * a.rows_per_wg;
+    // the rows of a tile are loaded one batch ahead (issued before phase 2, consumed after the next barrier pair)
+    float nz0, nz1p, ng0, ng1p;
+    auto fetch = [&](int64_t first) {
+        const int64_t r = first + 32 * wave + col, rc = r < a.n_rows ? r : a.n_rows - 1;
+        nz0 = a.z[rc];
+        nz1p = a.z[a.n_rows + rc];
+        ng0 = a.g[rc];
+        ng1p = a.g[a.n_rows + rc];
+    };
+    fetch(wg_row0 < a.n_rows ? wg_row0 : 0);
     for (int64_t row0 = wg_row0; row0 < wg_row0 + a.rows_per_wg && row0 < a.n_rows; row0 += BW_ROWS) {
         // ---------------------------------------------------------------- phase 1: this wave's tile, rows on lanes
         const int64_t row = row0 + 32 * wave + col;
         const bool valid = row < a.n_rows;
-        const int64_t rr = valid ? row : a.n_rows - 1;
-        const float z0 = a.z[rr], z1p = a.z[a.n_rows + rr];
-        const float g0 = valid ? a.g[rr] : 0.0f, g1p = valid ? a.g[a.n_rows + rr] : 0.0f;
+        const float z0 = nz0, z1p = nz1p;
+        const float g0 = valid ? ng0 : 0.0f, g1p = valid ? ng1p : 0.0f;
         const float gl_row = valid ? a.gl : 0.0f;
         f32x16 a0, a1, a2, a3;                                                                // (1)
 #pragma unroll
@@ -124,7 +133,7 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
             const float* w1 = lds + B_W1 + half;
             const float* bb1 = lds + B_B1 + half;
             const float* wi = lds + B_W2 + col * WS + half;                                   // W2[32 t + col][2 s + half]
-#pragma unroll 4
+#pragma unroll 8
             for (int s = 0; s < 64; ++s) {
                 const float h1 = __builtin_fmaxf(__builtin_fmaf(w1[2 * s], z0, bb1[2 * s]), 0.0f);
                 a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wi[2 * s], h1, a0, 0, 0, 0);
@@ -215,13 +224,14 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
             a.g[row] = dz1;
             a.g[a.n_rows + row] = g0 + lds[B_DZ0 + 32 * wave + col];
         }
+        if (row0 + BW_ROWS < wg_row0 + a.rows_per_wg && row0 + BW_ROWS < a.n_rows) fetch(row0 + BW_ROWS);
         // ---------------------------------------------------------------- phase 2: neurons 32 wave.., all rows of the batch
         {
             const float* sa = lds + B_S + half * WS + 32 * wave + col;                        // a2[32 wave + col][row 2 s + half]
             const float* zs = lds + B_Z0 + half;
             const float* ds = lds + B_DSH + half;
             const float* dl = lds + B_DLS + half;
-#pragma unroll 4
+#pragma unroll 8
             for (int s = 0; s < 64; ++s) {
                 const float a2v = sa[2 * s * WS];
                 const float dsr = ds[2 * s], dlr = dl[2 * s], zr = zs[2 * s];

@@ -46,7 +46,21 @@ def resample(W, N, u0=None):
 def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
               filelocation, global_frequency, step_size, batch_size, base, Train_step, *,
               num_layers=32, seed=None, device=None, chain0=0, return_device=False, verbose=True, flow=None,
-              lr=5e-4, weight_decay=1e-5, state_out=None):
+              lr=5e-4, weight_decay=1e-5, state_out=None, path="auto", **generic_kw):
+    if path not in ("auto", "fused", "generic"):
+        raise ValueError("path must be 'auto', 'fused' or 'generic'")
+    from . import generic
+    desc = generic.try_descriptor(ABCset)
+    builtin = isinstance(desc, _capi.Model) and desc.sim_kind in (_capi.SIM_ABS_GAUSS, _capi.SIM_GK) and \
+        generic.dist_descriptor(Local_Proposal, desc.theta_dim) is not None
+    if path == "generic" or (path == "auto" and not builtin):
+        # a Model given as callbacks (or a CompiledModel): pools, local moves and weights through the Model's own methods
+        return generic.run_glmcmc_nf(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, filelocation, global_frequency,
+                                     step_size, batch_size, base, Train_step, num_layers=num_layers, seed=seed, device=device,
+                                     chain0=chain0, return_device=return_device, verbose=verbose, flow=flow, lr=lr,
+                                     weight_decay=weight_decay, state_out=state_out, **generic_kw)
+    if generic_kw:
+        raise TypeError("unexpected keyword arguments for the fused path: %s" % sorted(generic_kw))
     lib = _capi.lib()
     model = engine.model_descriptor(ABCset)
     local = Local_Proposal.descriptor()

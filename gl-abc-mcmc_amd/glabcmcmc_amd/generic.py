@@ -318,6 +318,148 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     return _host.finish(hist, chains, single, filelocation, csv_variant, verbose and single, return_device)
 
 
+# ----------------------------------------------------------------------------------------------------------- GLMCMC_NF
+def run_glmcmc_nf(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, filelocation, global_frequency, step_size,
+                  batch_size, base, Train_step, *, num_layers=32, seed=None, device=None, chain0=0, return_device=False,
+                  verbose=True, flow=None, lr=5e-4, weight_decay=1e-5, state_out=None, callback_device="auto"):
+    """GLMCMC_NF (GLMCMC_NFs.py:43-186) with the Model as callbacks.  The flow's kernels are the fused path's
+    (glabc_nf_sample for the pools, glabc_nf_log_prob_indexed for NF_model.log_prob(Theta_old), HipAdam for the training
+    step); the Model is evaluated through its own methods: once per pool on all of its rows (generate_samples, prior_log_prob,
+    calculate_log_kernel: GLMCMC_NFs.py:73-85,128-140) and once per iteration on the local-move candidates (:142-146); the
+    iSIR index / MH test / state update / Theta_Re row are glabc_propose + glabc_select as in GLMCMC, with the chain's next
+    pool slice as the candidates of a global move and NF_model.log_prob(Theta_old) as the current state's proposal density
+    (recomputed weight every global move, :96-101).  Same schedule as the fused path: every chain owns a pool, all pools are
+    redrawn as soon as one chain has used its step_size slices, one shared flow."""
+    from .flows import HipAdam, RealNVP
+    from .GLMCMC_NFs import resample
+    lib = _capi.lib()
+    dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
+    n, d, yd = chains.n, chains.d, chains.yd
+    if d != 2:
+        raise ValueError("the RealNVP of GLMCMC_NF is built for theta_dim = 2 (MLP([1,128,128,2]), GLMCMC_NFs.py:56)")
+    N, S = int(batch_size), int(step_size)
+    P, R = N * S, N * n
+    rows = P * n
+    key = engine.draw_seed(seed)
+    model = ModelCallbacks(ABCset, dev, callback_device)
+    local_desc = dist_descriptor(Local_Proposal, d)
+    local_cb = ProposalCallbacks(Local_Proposal, dev) if local_desc is None else None
+    if flow is None:
+        flow = RealNVP(num_layers, base if isinstance(base, torch.nn.Module) else None)
+    flow = flow.to(dev)
+    optimizer = HipAdam(flow, lr=lr, weight_decay=weight_decay)                                  # GLMCMC_NFs.py:63
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(key & 0x7FFFFFFFFFFFFFFF)
+
+    f32 = dict(dtype=torch.float32, device=dev)
+    theta_prop = torch.zeros(R, d, **f32)
+    log_q = torch.zeros(R, **f32)
+    nd = model.noise_dim
+    sim_noise = torch.zeros(R, nd, **f32) if nd else None
+    log_u = torch.zeros(n, **f32)
+    u_res = torch.zeros(n, dtype=torch.float64, device=dev)
+    is_global = torch.zeros(n, dtype=torch.int32, device=dev)
+    model.probe(chains.theta.t(), chains.y.t())
+    prior_cur = model.prior(chains.theta.t().contiguous()).clone()
+    kern_cur = model.kernel(chains.y.t().contiguous()).clone()
+    hist = _host.allocate_history(num_ite, chains, True)
+    kk = torch.zeros(n, dtype=torch.int64, device=dev)
+    log_q_old = torch.empty(n, **f32)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    chain_ids = torch.arange(n, device=dev).view(1, n)
+    slot = torch.arange(N, device=dev).view(N, 1)
+    pool, losses = {}, []
+
+    def draw_pool(refresh_id):
+        flow.eval()
+        z, lq = flow.sample(rows, seed=key ^ 0x9E3779B97F4A7C15, row0=refresh_id * rows)          # row r = p*n + c
+        th = z.contiguous()
+        eps = torch.randn(rows, nd, generator=gen, device=dev) if nd else None
+        x = model.simulate(th, eps)                                                               # :73-76 / 128-131
+        pool.update(theta=th, lq=lq, x=x, prior=model.prior(th), kern=model.kernel(x))             # :77-78 / 132-133
+        kk.zero_()
+
+    def flow_state():
+        blob = flow.packed_params()
+        return blob, flow.descriptor(blob)
+
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def log_prob_all():
+        with torch.cuda.device(dev):
+            _capi.check(lib.glabc_nf_log_prob(C.byref(fdesc), chains.theta.data_ptr(), n, log_q_old.data_ptr(), stream),
+                        "glabc_nf_log_prob")
+
+    io = _capi.StepIO()
+    io.n_prop, io.theta_dim, io.y_dim, io.noise_dim = N, d, yd, nd
+    io.theta_prop, io.log_q = theta_prop.data_ptr(), log_q.data_ptr()
+    io.sim_noise = sim_noise.data_ptr() if nd else None
+    io.log_u, io.u_res, io.is_global = log_u.data_ptr(), u_res.data_ptr(), is_global.data_ptr()
+    io.prior_cur, io.kern_cur, io.q_cur = prior_cur.data_ptr(), kern_cur.data_ptr(), log_q_old.data_ptr()
+    cs = chains.struct()
+    run_ = _capi.Run()
+    run_.seed, run_.n_steps, run_.global_frequency, run_.batch_size, run_.hist_stride = key, 1, float(global_frequency), N, n
+    hist_ptr, hist_row_bytes = hist.data_ptr(), hist[0].numel() * 4
+    lp = C.byref(local_desc) if local_desc is not None else None
+
+    refresh, num_train = 0, 0
+    draw_pool(refresh)
+    blob, fdesc = flow_state()
+    log_prob_all()
+    countdown = S
+    with torch.cuda.device(dev):
+        for i in range(1, num_ite):
+            run_.step0, run_.history = i, hist_ptr + i * hist_row_bytes
+            _capi.check(lib.glabc_propose(_capi.ALGO_GLMCMC, lp, None, C.byref(cs), C.byref(run_), C.byref(io), stream),
+                        "glabc_propose")                                                        # branch, uniforms, local candidates
+            glob = (is_global & 1) != 0
+            if local_cb is not None:                                                              # :142
+                theta_prop[:n] = local_cb.sample(n) + chains.theta.t()
+            src = (((kk.clamp(max=S - 1) * N).view(1, n) + slot) * n + chain_ids).view(-1)        # the chains' next slices, :93-95
+            loc = ~glob
+            th_loc = torch.where(loc.view(-1, 1), theta_prop[:n], pool["theta"][src[:n]])         # local move: row 0 of the chain
+            theta_prop.copy_(pool["theta"][src])
+            theta_prop[:n] = th_loc
+            y_loc = model.simulate(th_loc, sim_noise[:n].contiguous() if nd else None)            # :143-144
+            y_prop, prior_prop, kern_prop = pool["x"][src], pool["prior"][src], pool["kern"][src]
+            y_prop[:n] = torch.where(loc.view(-1, 1), y_loc, y_prop[:n])
+            prior_prop[:n] = torch.where(loc, model.prior(th_loc), prior_prop[:n])
+            kern_prop[:n] = torch.where(loc, model.kernel(y_loc), kern_prop[:n])
+            log_q.copy_(pool["lq"][src])
+            chains.flags.fill_(_capi.FLAG_LOCAL)                 # the current state's weight is recomputed at every global move, :96-101
+            io.y_prop, io.prior_prop, io.kern_prop = y_prop.data_ptr(), prior_prop.data_ptr(), kern_prop.data_ptr()
+            _capi.check(lib.glabc_select(_capi.ALGO_GLMCMC, None, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_select")
+            kk += glob                                                                            # :111
+            moved = (is_global & 2) != 0                                                          # NF_model.log_prob(Theta_old), :96-98
+            order = torch.argsort(moved, descending=True, stable=True).to(torch.int32)
+            count.copy_(moved.sum().to(torch.int32).view(1))
+            _capi.check(lib.glabc_nf_log_prob_indexed(C.byref(fdesc), chains.theta.data_ptr(), n, order.data_ptr(),
+                                                      count.data_ptr(), n, log_q_old.data_ptr(), stream),
+                        "glabc_nf_log_prob_indexed")
+            countdown -= 1
+            if countdown > 0:
+                continue
+            used = int(kk.max().item())
+            if used < S:                                                                          # :112
+                countdown = S - used
+                continue
+            if num_train < Train_step:                                                            # :114-124
+                w = torch.exp(pool["prior"] + pool["kern"] - pool["lq"])                          # weight0, :79-85
+                w = torch.where(torch.isnan(w), torch.zeros_like(w), w)
+                idx = resample(w / torch.sum(w), rows)
+                losses.append(optimizer.step(pool["theta"][idx]))
+                num_train += 1
+                blob, fdesc = flow_state()
+                log_prob_all()
+            refresh += 1
+            draw_pool(refresh)
+            countdown = S
+    if state_out is not None:
+        state_out.update(chains=chains, flow=flow, loss_hist=losses, num_train=num_train, pools_drawn=refresh + 1,
+                         callback_device=model.where)
+    return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)
+
+
 # ----------------------------------------------------------------------------------------------------------- GLMALA
 def _numerical_gradient(model, theta, num, eps_sq, gen, seeds, d_step=1e-1):
     """numberical_gradient_logABC (GLMALA.py:46-95) for a batch of rows: central difference (step 0.1) of the synthetic

@@ -249,3 +249,44 @@ def test_log_prob_cache_follows_the_moved_chains(hip, oracle):
         total += k
     assert total > n // 2
     assert np.array_equal(bits(cache.cpu().numpy()), bits(full_log_prob(hc.theta)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["torch", "compiled"])
+def test_glmcmc_nf_with_a_callback_model_has_the_law_of_the_fused_path(hip, kind):
+    """run_glmcmc_nf with a Model that has no built-in descriptor -- a user's plain-torch class, and a CompiledModel (C
+    simulator) -- goes through generic.run_glmcmc_nf (pools and local moves evaluated by the Model's own methods, selection by
+    glabc_propose / glabc_select, the flow and its training by the same kernels): same shapes / side effects, the flow
+    trains, and pooled E|theta|, E theta^2 and the move rate agree with the fused path within Monte-Carlo error."""
+    import glabcmcmc_amd as g
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    from glabcmcmc_amd.examples.UserModel import TorchMixture
+    eps, n, T, gf, S, N, train = 0.3, 4096, 100, 0.7, 4, 5, 6
+    lp = g.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35])))
+    if kind == "torch":
+        user = TorchMixture(2, eps)
+    else:
+        src = ("GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)\n"
+               "{ for (int j = 0; j < 2; ++j) y[j] = fabsf(theta[j]) + 0.2236068f * eps[j]; }\n")
+        user = g.CompiledModel(2, 2, src, g.DiagGaussian(2, torch.zeros(2), torch.zeros(2)), [1.5, 1.5], eps)
+    gen = torch.Generator().manual_seed(3)
+    th0 = 1.3 * (torch.randint(0, 2, (n, 2), generator=gen).float() * 2 - 1)
+    y0 = th0.abs() + 0.2236 * torch.randn(n, 2, generator=gen)
+    res = {}
+    for name, m in (("fused", Mixture_set(eps)), ("generic", user)):
+        st = {}
+        torch.manual_seed(5)
+        out = g.MCMCRunner(m).run_glmcmc_nf(T + 1, th0, y0, gf, lp, None, N, S, train, output_file=None, num_layers=4, seed=7,
+                                            state_out=st, lr=5e-3, verbose=False, return_device=True)
+        assert out.shape == (T + 1, n, 2) and torch.isfinite(out).all()
+        assert st["num_train"] == train and np.isfinite(st["loss_hist"]).all() and st["loss_hist"][-1] < st["loss_hist"][0]
+        late = out[T // 2:]
+        res[name] = (late.abs().mean(dim=(0, 2)).cpu().numpy(), (late ** 2).mean(dim=(0, 2)).cpu().numpy(),
+                     st["chains"].n_moves.cpu().numpy().astype(np.float64) / T)
+    assert "callback_device" in st                                             # the second run took the callback path
+    for a, b, what in zip(res["fused"], res["generic"], ("E|theta|", "E theta^2", "move rate")):
+        se = np.sqrt(a.var(ddof=1) / n + b.var(ddof=1) / n)
+        assert abs(a.mean() - b.mean()) < 5 * se, (what, a.mean(), b.mean(), se)
+    one = g.GLMCMC_NF(user, 30, torch.tensor([0.0, 0.0]), torch.tensor([[1.5, 1.5]]), lp, None, 0.5, 3, 5, None, 2,
+                      num_layers=2, seed=2, verbose=False)
+    assert one.shape == (30, 2) and one.device.type == "cpu"

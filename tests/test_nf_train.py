@@ -194,8 +194,8 @@ def test_hip_training_steps_follow_torch_training_steps(hip):
         lt.backward()
         topt.step()
         lh = opt.step(x)
-        losses.append((lh, float(lt)))
-        assert abs(lh - float(lt)) <= 2e-5 * abs(float(lt))
+        losses.append((lh, float(lt.detach())))
+        assert abs(lh - float(lt.detach())) <= 2e-5 * abs(float(lt.detach()))
     for a, b in zip(flow.parameters(), ref.parameters()):
         # one Adam step moves a parameter by ~lr whatever the size of its gradient: entries whose gradient is at the noise
         # level of the float32 sums may differ by a fraction of lr, everything else by far less
