@@ -37,7 +37,22 @@ ISIR_STREAM, POOL_STREAM, KDE_STREAM = 0x9E3779B97F4A7C15, 0x5851F42D4C957F2D, 0
 
 def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_ISIR_prop,
             filelocation, global_frequency, step_size, batch_size, alpha, hat_eps_T, device=None, *,
-            seed=None, chain0=0, return_device=False, verbose=True, max_train=None, state_out=None):
+            seed=None, chain0=0, return_device=False, verbose=True, max_train=None, state_out=None, path="auto", **generic_kw):
+    if path not in ("auto", "fused", "generic"):
+        raise ValueError("path must be 'auto', 'fused' or 'generic'")
+    from . import generic
+    desc = generic.try_descriptor(ABCset)
+    builtin = isinstance(desc, _capi.Model) and desc.sim_kind in (_capi.SIM_ABS_GAUSS, _capi.SIM_GK) and \
+        generic.dist_descriptor(Local_Proposal, desc.theta_dim) is not None and \
+        generic.dist_descriptor(Initial_ISIR_prop, desc.theta_dim) is not None
+    if path == "generic" or (path == "auto" and not builtin):
+        # a Model (or proposals) given as callbacks: generic.run_aglmcmc
+        return generic.run_aglmcmc(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_ISIR_prop, filelocation,
+                                   global_frequency, step_size, batch_size, alpha, hat_eps_T, seed=seed, device=device,
+                                   chain0=chain0, return_device=return_device, verbose=verbose, max_train=max_train,
+                                   state_out=state_out, **generic_kw)
+    if generic_kw:
+        raise TypeError("unexpected keyword arguments for the fused path: %s" % sorted(generic_kw))
     lib = _capi.lib()
     model = engine.model_descriptor(ABCset)
     local = Local_Proposal.descriptor()

@@ -318,7 +318,120 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     return _host.finish(hist, chains, single, filelocation, csv_variant, verbose and single, return_device)
 
 
-# ----------------------------------------------------------------------------------------------------------- GLMCMC_NF
+# ------------------------------------------------------------------------------------------- pool samplers (GLMCMC_NF, AGLMCMC)
+class PoolSampler:
+    """One chain-state + iteration engine shared by the callback forms of GLMCMC_NF and AGLMCMC: every chain owns a pool of
+    P = batch_size*step_size proposals (row r = p*n + c), a global move is the iSIR step against the chain's next slice
+    (GLMCMC_NFs.py:90-111 / AGLMCMC.py:125-172), a local move the random-walk MH step (:142-152 / :251-272).  The Model's
+    methods evaluate a pool once (`load_pool`) and the local-move candidates every iteration; glabc_propose draws, glabc_select
+    decides.  `log_q_old` (the proposal's log-density of the current states) is the caller's to keep current."""
+
+    def __init__(self, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, global_frequency, step_size, batch_size,
+                 seed, device, chain0, callback_device):
+        self.lib = _capi.lib()
+        self.dev, self.chains, self.single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
+        dev, chains = self.dev, self.chains
+        self.n, self.d, self.yd = chains.n, chains.d, chains.yd
+        n, d = self.n, self.d
+        self.N, self.S = int(batch_size), int(step_size)
+        self.rows = self.N * self.S * n
+        R = self.N * n
+        self.key = engine.draw_seed(seed)
+        self.model = ModelCallbacks(ABCset, dev, callback_device)
+        self.local_desc = dist_descriptor(Local_Proposal, d)
+        self.local_cb = ProposalCallbacks(Local_Proposal, dev) if self.local_desc is None else None
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(self.key & 0x7FFFFFFFFFFFFFFF)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.theta_prop = torch.zeros(R, d, **f32)
+        self.log_q = torch.zeros(R, **f32)
+        self.nd = self.model.noise_dim
+        self.sim_noise = torch.zeros(R, self.nd, **f32) if self.nd else None
+        self.log_u = torch.zeros(n, **f32)
+        self.u_res = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.is_global = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.model.probe(chains.theta.t(), chains.y.t())
+        self.prior_cur = self.model.prior(chains.theta.t().contiguous()).clone()
+        self.kern_cur = self.model.kernel(chains.y.t().contiguous()).clone()
+        self.hist = _host.allocate_history(num_ite, chains, True)
+        self.kk = torch.zeros(n, dtype=torch.int64, device=dev)
+        self.log_q_old = torch.zeros(n, **f32)
+        self._chain_ids = torch.arange(n, device=dev).view(1, n)
+        self._slot = torch.arange(self.N, device=dev).view(self.N, 1)
+        self.pool = {}
+        io = self.io = _capi.StepIO()
+        io.n_prop, io.theta_dim, io.y_dim, io.noise_dim = self.N, d, self.yd, self.nd
+        io.theta_prop, io.log_q = self.theta_prop.data_ptr(), self.log_q.data_ptr()
+        io.sim_noise = self.sim_noise.data_ptr() if self.nd else None
+        io.log_u, io.u_res, io.is_global = self.log_u.data_ptr(), self.u_res.data_ptr(), self.is_global.data_ptr()
+        io.prior_cur, io.kern_cur = self.prior_cur.data_ptr(), self.kern_cur.data_ptr()
+        self.cs = chains.struct()
+        run_ = self.run_ = _capi.Run()
+        run_.seed, run_.n_steps, run_.global_frequency, run_.batch_size, run_.hist_stride = \
+            self.key, 1, float(global_frequency), self.N, n
+        self._hist_ptr, self._hist_row_bytes = self.hist.data_ptr(), self.hist[0].numel() * 4
+        self.stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        self._countdown = self.S
+
+    def load_pool(self, theta_rows, lq):
+        """theta_rows (rows, d), lq (rows,): simulate and evaluate the pool (GLMCMC_NFs.py:73-78 / AGLMCMC.py:90-100)"""
+        eps = torch.randn(self.rows, self.nd, generator=self.gen, device=self.dev) if self.nd else None
+        x = self.model.simulate(theta_rows, eps)
+        self.pool = dict(theta=theta_rows, lq=lq, x=x, prior=self.model.prior(theta_rows), kern=self.model.kernel(x))
+        self.kk.zero_()
+        self._countdown = self.S
+        return self.pool
+
+    def pool_weights(self):
+        """weight0 = exp(prior + kernel - log q), NaN -> 0 (GLMCMC_NFs.py:79-85)"""
+        w = torch.exp(self.pool["prior"] + self.pool["kern"] - self.pool["lq"])
+        return torch.where(torch.isnan(w), torch.zeros_like(w), w)
+
+    def step(self, i):
+        """iteration i for every chain; returns the mask of the chains that moved (on the device)"""
+        lib, n, N, io, run_, pool, chains = self.lib, self.n, self.N, self.io, self.run_, self.pool, self.chains
+        run_.step0, run_.history = i, self._hist_ptr + i * self._hist_row_bytes
+        lp = C.byref(self.local_desc) if self.local_desc is not None else None
+        _capi.check(lib.glabc_propose(_capi.ALGO_GLMCMC, lp, None, C.byref(self.cs), C.byref(run_), C.byref(io), self.stream),
+                    "glabc_propose")                                                            # branch, uniforms, local candidates
+        glob = (self.is_global & 1) != 0
+        if self.local_cb is not None:
+            self.theta_prop[:n] = self.local_cb.sample(n) + chains.theta.t()
+        src = (((self.kk.clamp(max=self.S - 1) * N).view(1, n) + self._slot) * n + self._chain_ids).view(-1)   # next slices
+        loc = ~glob
+        th_loc = torch.where(loc.view(-1, 1), self.theta_prop[:n], pool["theta"][src[:n]])       # local move: row 0 of the chain
+        self.theta_prop.copy_(pool["theta"][src])
+        self.theta_prop[:n] = th_loc
+        y_loc = self.model.simulate(th_loc, self.sim_noise[:n].contiguous() if self.nd else None)
+        y_prop, prior_prop, kern_prop = pool["x"][src], pool["prior"][src], pool["kern"][src]
+        y_prop[:n] = torch.where(loc.view(-1, 1), y_loc, y_prop[:n])
+        prior_prop[:n] = torch.where(loc, self.model.prior(th_loc), prior_prop[:n])
+        kern_prop[:n] = torch.where(loc, self.model.kernel(y_loc), kern_prop[:n])
+        self.log_q.copy_(pool["lq"][src])
+        chains.flags.fill_(_capi.FLAG_LOCAL)        # the current state's weight is recomputed at every global move
+        io.y_prop, io.prior_prop, io.kern_prop = y_prop.data_ptr(), prior_prop.data_ptr(), kern_prop.data_ptr()
+        io.q_cur = self.log_q_old.data_ptr()
+        _capi.check(lib.glabc_select(_capi.ALGO_GLMCMC, None, C.byref(self.cs), C.byref(run_), C.byref(io), self.stream),
+                    "glabc_select")
+        self.kk += glob
+        self._countdown -= 1
+        return (self.is_global & 2) != 0
+
+    def pool_used_up(self):
+        """has some chain used its step_size slices?  (a chain uses at most one per iteration: the device is asked -- a
+        synchronisation -- only when that has become possible)"""
+        if self._countdown > 0:
+            return False
+        used = int(self.kk.max().item())
+        if used < self.S:
+            self._countdown = self.S - used
+            return False
+        return True
+
+    def finish(self, filelocation, csv_variant, verbose, return_device):
+        return _host.finish(self.hist, self.chains, self.single, filelocation, csv_variant, verbose and self.single, return_device)
+
+
 def run_glmcmc_nf(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, filelocation, global_frequency, step_size,
                   batch_size, base, Train_step, *, num_layers=32, seed=None, device=None, chain0=0, return_device=False,
                   verbose=True, flow=None, lr=5e-4, weight_decay=1e-5, state_out=None, callback_device="auto"):
@@ -326,138 +439,150 @@ def run_glmcmc_nf(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, fil
     (glabc_nf_sample for the pools, glabc_nf_log_prob_indexed for NF_model.log_prob(Theta_old), HipAdam for the training
     step); the Model is evaluated through its own methods: once per pool on all of its rows (generate_samples, prior_log_prob,
     calculate_log_kernel: GLMCMC_NFs.py:73-85,128-140) and once per iteration on the local-move candidates (:142-146); the
-    iSIR index / MH test / state update / Theta_Re row are glabc_propose + glabc_select as in GLMCMC, with the chain's next
-    pool slice as the candidates of a global move and NF_model.log_prob(Theta_old) as the current state's proposal density
-    (recomputed weight every global move, :96-101).  Same schedule as the fused path: every chain owns a pool, all pools are
-    redrawn as soon as one chain has used its step_size slices, one shared flow."""
+    iSIR index / MH test / state update / Theta_Re row are glabc_propose + glabc_select (PoolSampler).  Same schedule as the
+    fused path: every chain owns a pool, all pools are redrawn as soon as one chain has used its step_size slices, one flow."""
     from .flows import HipAdam, RealNVP
     from .GLMCMC_NFs import resample
-    lib = _capi.lib()
-    dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
-    n, d, yd = chains.n, chains.d, chains.yd
-    if d != 2:
+    ps = PoolSampler(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, global_frequency, step_size, batch_size, seed,
+                     device, chain0, callback_device)
+    if ps.d != 2:
         raise ValueError("the RealNVP of GLMCMC_NF is built for theta_dim = 2 (MLP([1,128,128,2]), GLMCMC_NFs.py:56)")
-    N, S = int(batch_size), int(step_size)
-    P, R = N * S, N * n
-    rows = P * n
-    key = engine.draw_seed(seed)
-    model = ModelCallbacks(ABCset, dev, callback_device)
-    local_desc = dist_descriptor(Local_Proposal, d)
-    local_cb = ProposalCallbacks(Local_Proposal, dev) if local_desc is None else None
+    lib, dev, n, rows, chains = ps.lib, ps.dev, ps.n, ps.rows, ps.chains
     if flow is None:
         flow = RealNVP(num_layers, base if isinstance(base, torch.nn.Module) else None)
     flow = flow.to(dev)
     optimizer = HipAdam(flow, lr=lr, weight_decay=weight_decay)                                  # GLMCMC_NFs.py:63
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(key & 0x7FFFFFFFFFFFFFFF)
-
-    f32 = dict(dtype=torch.float32, device=dev)
-    theta_prop = torch.zeros(R, d, **f32)
-    log_q = torch.zeros(R, **f32)
-    nd = model.noise_dim
-    sim_noise = torch.zeros(R, nd, **f32) if nd else None
-    log_u = torch.zeros(n, **f32)
-    u_res = torch.zeros(n, dtype=torch.float64, device=dev)
-    is_global = torch.zeros(n, dtype=torch.int32, device=dev)
-    model.probe(chains.theta.t(), chains.y.t())
-    prior_cur = model.prior(chains.theta.t().contiguous()).clone()
-    kern_cur = model.kernel(chains.y.t().contiguous()).clone()
-    hist = _host.allocate_history(num_ite, chains, True)
-    kk = torch.zeros(n, dtype=torch.int64, device=dev)
-    log_q_old = torch.empty(n, **f32)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
-    chain_ids = torch.arange(n, device=dev).view(1, n)
-    slot = torch.arange(N, device=dev).view(N, 1)
-    pool, losses = {}, []
+    losses = []
 
     def draw_pool(refresh_id):
         flow.eval()
-        z, lq = flow.sample(rows, seed=key ^ 0x9E3779B97F4A7C15, row0=refresh_id * rows)          # row r = p*n + c
-        th = z.contiguous()
-        eps = torch.randn(rows, nd, generator=gen, device=dev) if nd else None
-        x = model.simulate(th, eps)                                                               # :73-76 / 128-131
-        pool.update(theta=th, lq=lq, x=x, prior=model.prior(th), kern=model.kernel(x))             # :77-78 / 132-133
-        kk.zero_()
+        z, lq = flow.sample(rows, seed=ps.key ^ 0x9E3779B97F4A7C15, row0=refresh_id * rows)       # :70-72 / 125-127
+        ps.load_pool(z.contiguous(), lq)
 
     def flow_state():
         blob = flow.packed_params()
         return blob, flow.descriptor(blob)
 
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-
     def log_prob_all():
         with torch.cuda.device(dev):
-            _capi.check(lib.glabc_nf_log_prob(C.byref(fdesc), chains.theta.data_ptr(), n, log_q_old.data_ptr(), stream),
+            _capi.check(lib.glabc_nf_log_prob(C.byref(fdesc), chains.theta.data_ptr(), n, ps.log_q_old.data_ptr(), ps.stream),
                         "glabc_nf_log_prob")
-
-    io = _capi.StepIO()
-    io.n_prop, io.theta_dim, io.y_dim, io.noise_dim = N, d, yd, nd
-    io.theta_prop, io.log_q = theta_prop.data_ptr(), log_q.data_ptr()
-    io.sim_noise = sim_noise.data_ptr() if nd else None
-    io.log_u, io.u_res, io.is_global = log_u.data_ptr(), u_res.data_ptr(), is_global.data_ptr()
-    io.prior_cur, io.kern_cur, io.q_cur = prior_cur.data_ptr(), kern_cur.data_ptr(), log_q_old.data_ptr()
-    cs = chains.struct()
-    run_ = _capi.Run()
-    run_.seed, run_.n_steps, run_.global_frequency, run_.batch_size, run_.hist_stride = key, 1, float(global_frequency), N, n
-    hist_ptr, hist_row_bytes = hist.data_ptr(), hist[0].numel() * 4
-    lp = C.byref(local_desc) if local_desc is not None else None
 
     refresh, num_train = 0, 0
     draw_pool(refresh)
     blob, fdesc = flow_state()
     log_prob_all()
-    countdown = S
     with torch.cuda.device(dev):
         for i in range(1, num_ite):
-            run_.step0, run_.history = i, hist_ptr + i * hist_row_bytes
-            _capi.check(lib.glabc_propose(_capi.ALGO_GLMCMC, lp, None, C.byref(cs), C.byref(run_), C.byref(io), stream),
-                        "glabc_propose")                                                        # branch, uniforms, local candidates
-            glob = (is_global & 1) != 0
-            if local_cb is not None:                                                              # :142
-                theta_prop[:n] = local_cb.sample(n) + chains.theta.t()
-            src = (((kk.clamp(max=S - 1) * N).view(1, n) + slot) * n + chain_ids).view(-1)        # the chains' next slices, :93-95
-            loc = ~glob
-            th_loc = torch.where(loc.view(-1, 1), theta_prop[:n], pool["theta"][src[:n]])         # local move: row 0 of the chain
-            theta_prop.copy_(pool["theta"][src])
-            theta_prop[:n] = th_loc
-            y_loc = model.simulate(th_loc, sim_noise[:n].contiguous() if nd else None)            # :143-144
-            y_prop, prior_prop, kern_prop = pool["x"][src], pool["prior"][src], pool["kern"][src]
-            y_prop[:n] = torch.where(loc.view(-1, 1), y_loc, y_prop[:n])
-            prior_prop[:n] = torch.where(loc, model.prior(th_loc), prior_prop[:n])
-            kern_prop[:n] = torch.where(loc, model.kernel(y_loc), kern_prop[:n])
-            log_q.copy_(pool["lq"][src])
-            chains.flags.fill_(_capi.FLAG_LOCAL)                 # the current state's weight is recomputed at every global move, :96-101
-            io.y_prop, io.prior_prop, io.kern_prop = y_prop.data_ptr(), prior_prop.data_ptr(), kern_prop.data_ptr()
-            _capi.check(lib.glabc_select(_capi.ALGO_GLMCMC, None, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_select")
-            kk += glob                                                                            # :111
-            moved = (is_global & 2) != 0                                                          # NF_model.log_prob(Theta_old), :96-98
-            order = torch.argsort(moved, descending=True, stable=True).to(torch.int32)
-            count.copy_(moved.sum().to(torch.int32).view(1))
+            moved = ps.step(i)
+            order = torch.argsort(moved, descending=True, stable=True).to(torch.int32)            # NF_model.log_prob(Theta_old), :96-98:
+            count.copy_(moved.sum().to(torch.int32).view(1))                                      # only where the state changed
             _capi.check(lib.glabc_nf_log_prob_indexed(C.byref(fdesc), chains.theta.data_ptr(), n, order.data_ptr(),
-                                                      count.data_ptr(), n, log_q_old.data_ptr(), stream),
+                                                      count.data_ptr(), n, ps.log_q_old.data_ptr(), ps.stream),
                         "glabc_nf_log_prob_indexed")
-            countdown -= 1
-            if countdown > 0:
-                continue
-            used = int(kk.max().item())
-            if used < S:                                                                          # :112
-                countdown = S - used
+            if not ps.pool_used_up():                                                             # :112
                 continue
             if num_train < Train_step:                                                            # :114-124
-                w = torch.exp(pool["prior"] + pool["kern"] - pool["lq"])                          # weight0, :79-85
-                w = torch.where(torch.isnan(w), torch.zeros_like(w), w)
+                w = ps.pool_weights()
                 idx = resample(w / torch.sum(w), rows)
-                losses.append(optimizer.step(pool["theta"][idx]))
+                losses.append(optimizer.step(ps.pool["theta"][idx]))
                 num_train += 1
                 blob, fdesc = flow_state()
                 log_prob_all()
             refresh += 1
             draw_pool(refresh)
-            countdown = S
     if state_out is not None:
         state_out.update(chains=chains, flow=flow, loss_hist=losses, num_train=num_train, pools_drawn=refresh + 1,
+                         callback_device=ps.model.where)
+    return ps.finish(filelocation, "global", verbose, return_device)
+
+
+def run_aglmcmc(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_ISIR_prop, filelocation, global_frequency,
+                step_size, batch_size, alpha, hat_eps_T, *, seed=None, device=None, chain0=0, return_device=False, verbose=True,
+                max_train=None, state_out=None, callback_device="auto"):
+    """AGLMCMC (AGLMCMC.py:44-289) with the Model as callbacks: PoolSampler for the iterations, the Model's discrepancy /
+    calculate_log_kernel_dis (or calculate_log_kernel(y, epsilon)) / prior_log_prob for the annealed training weights
+    (:179-211), the build's KernelDensity kernels for the adaptive proposal (:214-229).  Same schedule and the same max_train
+    rule as the fused path (AGLMCMC.py of the build)."""
+    import warnings
+    from .kernel_density import KernelDensity
+    ps = PoolSampler(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, global_frequency, step_size, batch_size, seed,
+                     device, chain0, callback_device)
+    dev, n, d, rows, chains, model = ps.dev, ps.n, ps.d, ps.rows, ps.chains, ps.model
+    if not hasattr(ABCset, "discrepancy"):
+        raise TypeError("AGLMCMC needs Model.discrepancy (AGLMCMC.py:93)")
+    isir = ProposalCallbacks(Initial_ISIR_prop, dev)
+
+    def discrepancy(y):
+        return model._call(lambda cuda: model._back(ABCset.discrepancy(y if cuda else y.cpu()), y.shape[0])).view(-1)
+
+    def kernel_of_discrepancy(dis, x, eps):                                                       # calculate_log_kernel_dis, :199
+        if hasattr(ABCset, "calculate_log_kernel_dis"):
+            return model._call(lambda cuda: model._back(ABCset.calculate_log_kernel_dis(dis if cuda else dis.cpu(), eps),
+                                                        dis.shape[0])).view(-1)
+        return model._call(lambda cuda: model._back(ABCset.calculate_log_kernel(x if cuda else x.cpu(), eps), x.shape[0])).view(-1)
+
+    def load(theta_rows, lq):
+        pool = ps.load_pool(theta_rows, lq)
+        pool["dis"] = discrepancy(pool["x"])                                                      # :93 / 236
+
+    th, lq = isir.forward(rows)                                                                   # :80-81
+    load(th, lq)
+    KDE, kde_rows, warned = None, 0, False
+    num_train, eps_num, hat_eps = 0, 0, 1000000.0                                                 # :119
+    with torch.cuda.device(dev):
+        for i in range(1, num_ite):
+            if KDE is None:                                                                       # :137-140
+                ps.log_q_old.copy_(isir.log_prob(chains.theta.t().contiguous()))
+            else:
+                ps.log_q_old.copy_(KDE.log_prob_soa(chains.theta))
+            ps.step(i)
+            if not ps.pool_used_up():                                                             # :175
+                continue
+            pool = ps.pool
+            dis0 = pool["dis"]
+            if hat_eps > hat_eps_T:                                                               # :179-196
+                eps_num += 1
+                num_a = torch.sum(dis0 < hat_eps)
+                valid = dis0[~torch.isnan(dis0)]
+                if valid.numel() > 0:
+                    q = torch.clamp((alpha * num_a / valid.shape[0]).to(dis0.dtype), 0.0, 1.0)
+                    if valid.numel() > (1 << 24):                                                 # torch.quantile's input limit
+                        valid = valid[:: (valid.numel() >> 24) + 1]
+                    hat_eps = float(torch.quantile(valid, q))
+                hat_eps = max(hat_eps, float(hat_eps_T))
+            tw = torch.exp(pool["prior"] + kernel_of_discrepancy(dis0, pool["x"], hat_eps) - pool["lq"])   # :199-202
+            tw = torch.where(torch.isnan(tw), torch.zeros_like(tw), tw)
+            cap = rows if (max_train is None and n == 1) else int(8192 if max_train is None else max_train)
+            if cap < rows and not warned:
+                warned = True
+                warnings.warn('AGLMCMC: the adaptive KDE is trained on the first %d of %d pool rows (max_train)' % (cap, rows))
+            m = min(rows, cap)
+            keep = tw[:m] > 0                                                                     # :207-208
+            if bool(keep.any()):
+                KDE = KernelDensity(bandwidth='silverman', device=dev, seed=ps.key ^ 0xD1B54A32D192ED03)
+                KDE.fit(pool["theta"][:m][keep], tw[:m][keep])                                    # :211-215
+                num_train += 1
+            if KDE is None:                                                                       # no usable weights yet
+                th, lq = isir.forward(rows)
+                load(th, lq)
+                continue
+            got, parts = 0, []
+            while got < rows:                                                                     # :220-226
+                cand = KDE.sample_soa(4 * rows, row0=kde_rows).t().contiguous()
+                kde_rows += 4 * rows
+                sel = cand[model.prior(cand) > float(np.log(10 ** (-10)))]
+                parts.append(sel)
+                got += sel.shape[0]
+                if sel.shape[0] == 0 and len(parts) > 8:
+                    raise RuntimeError("the KDE proposal has left the prior's support")
+            theta_new = torch.cat(parts, 0)[:rows].contiguous()
+            load(theta_new, KDE.log_prob_soa(theta_new.t().contiguous()))                         # :229-249
+    if state_out is not None:
+        state_out.update(chains=chains, kde=KDE, hat_eps=hat_eps, num_train=num_train, eps_num=eps_num, pool=ps.pool,
                          callback_device=model.where)
-    return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)
+    return ps.finish(filelocation, "aglmcmc", verbose, return_device)
 
 
 # ----------------------------------------------------------------------------------------------------------- GLMALA

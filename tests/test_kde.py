@@ -298,3 +298,33 @@ def test_aglmcmc_follows_the_reference_chain(hip):
     assert first_bad == -1, "chains part at iteration %d: %s vs %s" % (first_bad, got[first_bad], ref[first_bad])
     assert st["num_train"] == int(g["kde_refits"])
     assert np.array_equal(bits(got[:40]), bits(ref[:40]))                  # before the first refit: bit for bit
+
+
+@pytest.mark.gpu
+def test_aglmcmc_with_a_callback_model(hip, tmp_path):
+    """run_aglmcmc with a user's plain-torch Model (no descriptor, no calculate_log_kernel_dis: the kernel of a discrepancy is
+    taken from calculate_log_kernel(y, epsilon)) goes through generic.run_aglmcmc: reference shapes and CSV, hat_eps annealed
+    to its target, KDE refits, and the pooled posterior agrees with the fused AGLMCMC on the built-in Model."""
+    from glabcmcmc_amd import AGLMCMC, MCMCRunner, distribution
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    from glabcmcmc_amd.examples.UserModel import TorchMixture
+    torch.manual_seed(0)
+    user = TorchMixture(2, 0.3)
+    lp = distribution.DiagGaussian(2, loc=torch.zeros(1, 2), log_scale=torch.log(torch.tensor([0.35, 0.35])))
+    ip = distribution.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.5, 0.5]))
+    theta0 = torch.tensor([1.5, 1.5])
+    st = {}
+    out = MCMCRunner(user, str(tmp_path)).run_aglmcmc(num_iterations=600, initial_theta=theta0, initial_y=user.generate_samples(theta0),
+                                                      global_frequency=0.6, local_proposal=lp, Initial_ISIR_prop=ip, batch_size=5,
+                                                      step_size=40, alpha=0.8, hat_eps_T=0.5, seed=3, verbose=False, state_out=st)
+    assert out.shape == (600, 2) and out.dtype == torch.float32 and torch.isfinite(out).all()
+    assert st["num_train"] >= 2 and st["kde"] is not None and "callback_device" in st
+    assert len(open(tmp_path / "glmcmc_results.csv").read().strip().split("\n")) == 600
+    n = 512
+    th0 = torch.zeros(n, 2) + 1.5
+    a = AGLMCMC(user, 1000, th0, user.generate_samples(th0), lp, ip, None, 0.6, 30, 5, 0.8, 0.5, seed=4, verbose=False, state_out=st)
+    b = AGLMCMC(Mixture_set(0.3), 1000, th0, user.generate_samples(th0), lp, ip, None, 0.6, 30, 5, 0.8, 0.5, seed=5, verbose=False)
+    assert a.shape == (1000, n, 2) and st["hat_eps"] == 0.5 and st["num_train"] >= 3
+    pa, pb = a[400:].abs().reshape(-1, 2), b[400:].abs().reshape(-1, 2)
+    assert torch.allclose(pa.mean(0), pb.mean(0), atol=0.03), (pa.mean(0), pb.mean(0))
+    assert torch.allclose(pa.std(0), pb.std(0), atol=0.03), (pa.std(0), pb.std(0))
