@@ -199,7 +199,7 @@ def test_hip_training_steps_follow_torch_training_steps(hip):
     for a, b in zip(flow.parameters(), ref.parameters()):
         # one Adam step moves a parameter by ~lr whatever the size of its gradient: entries whose gradient is at the noise
         # level of the float32 sums may differ by a fraction of lr, everything else by far less
-        d = (a - b).abs()
+        d = (a.detach() - b.detach()).abs()
         assert float(d.max()) <= 3 * 5e-4 and float(d.mean()) <= 2e-5, (float(d.max()), float(d.mean()))
     assert opt.steps == 3 and torch.equal(flow.packed_params(), opt.blob)
     # a NaN loss changes nothing (the reference skips backward and its optimizer.step() finds no gradients)
