@@ -19,7 +19,10 @@ Same positional signature as the reference function (``base`` is accepted for si
 Batched use (``Initial_theta`` of shape (C, d)): all chains share ONE flow; every chain owns a pool; pools are
 redrawn together as soon as one chain has used its ``step_size`` slices.  With C = 1 this is the reference's schedule.
 Keyword-only extras: ``num_layers`` (reference: 32, GLMCMC_NFs.py:51), ``seed``, ``device``, ``chain0``,
-``return_device``, ``verbose``, ``flow`` (reuse / inspect the model), ``lr`` / ``weight_decay`` (:63).
+``return_device``, ``verbose``, ``flow`` (reuse / inspect the model), ``lr`` / ``weight_decay`` (:63), ``process_group``
+(chains sharded over ranks that share the flow: the ranks refresh their pools together -- the fullest pool of any rank
+decides, one all-reduce of a word at each check -- and gradients are averaged over the ranks' pools before each Adam step;
+give every rank the same ``num_ite``, ``step_size`` and initial flow).
 """
 import ctypes as C
 
@@ -46,7 +49,7 @@ def resample(W, N, u0=None):
 def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
               filelocation, global_frequency, step_size, batch_size, base, Train_step, *,
               num_layers=32, seed=None, device=None, chain0=0, return_device=False, verbose=True, flow=None,
-              lr=5e-4, weight_decay=1e-5, state_out=None, path="auto", **generic_kw):
+              lr=5e-4, weight_decay=1e-5, state_out=None, path="auto", process_group=None, **generic_kw):
     if path not in ("auto", "fused", "generic"):
         raise ValueError("path must be 'auto', 'fused' or 'generic'")
     from . import generic
@@ -58,7 +61,7 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
         return generic.run_glmcmc_nf(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, filelocation, global_frequency,
                                      step_size, batch_size, base, Train_step, num_layers=num_layers, seed=seed, device=device,
                                      chain0=chain0, return_device=return_device, verbose=verbose, flow=flow, lr=lr,
-                                     weight_decay=weight_decay, state_out=state_out, **generic_kw)
+                                     weight_decay=weight_decay, state_out=state_out, process_group=process_group, **generic_kw)
     if generic_kw:
         raise TypeError("unexpected keyword arguments for the fused path: %s" % sorted(generic_kw))
     lib = _capi.lib()
@@ -82,13 +85,14 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     def draw_pool(refresh_id):
         rows = P * n
         flow.eval()
-        z, lq = flow.sample(rows, seed=key ^ 0x9E3779B97F4A7C15, row0=refresh_id * rows)        # row r = p*n + c
+        row0 = (refresh_id << 44) + chains.chain0 * P          # pool refresh, then this shard's rows: disjoint over ranks
+        z, lq = flow.sample(rows, seed=key ^ 0x9E3779B97F4A7C15, row0=row0)                      # row r = p*n + c
         theta = z.t().contiguous()                                                                 # [2][rows]
         x = torch.empty(chains.yd, rows, dtype=torch.float32, device=dev)
         w = torch.empty(rows, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _capi.check(lib.glabc_pool_weights(C.byref(model), theta.data_ptr(), lq.data_ptr(), rows, key ^ 0x5851F42D4C957F2D,
-                                               refresh_id * rows, x.data_ptr(), w.data_ptr(), stream), "glabc_pool_weights")
+                                               row0, x.data_ptr(), w.data_ptr(), stream), "glabc_pool_weights")
         pool.update(theta=theta, x=x, w=w, lq=lq)
         kk.zero_()
 
@@ -127,6 +131,10 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
         if countdown > 0:
             continue
         used = int(kk.max().item())
+        if process_group is not None:              # ranks sharing the flow refresh (and train) together: the fullest pool decides
+            from .parallel import max_over_ranks
+            used = max_over_ranks(used, None if process_group is True else process_group,
+                                  dev if torch.distributed.get_backend(None if process_group is True else process_group) == "nccl" else "cpu")
         if used < int(step_size):                                                                  # :112
             countdown = int(step_size) - used
             continue
@@ -135,7 +143,9 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
             Train_weight = w / torch.sum(w)
             idx = resample(Train_weight, w.numel())
             # zero_grad, forward_kld, backward unless the loss is NaN / inf, optimizer.step(): hand-written backward + Adam
-            loss = optimizer.step(pool["theta"][:, idx], chain_major=True)                         # (B11 is moot: see HipAdam)
+            loss = optimizer.step(pool["theta"][:, idx], chain_major=True, group=process_group,
+                                  via=None if process_group is None or torch.distributed.get_backend(
+                                      None if process_group is True else process_group) == "nccl" else "cpu")
             num_train += 1
             losses.append(loss)
             blob = flow.packed_params()

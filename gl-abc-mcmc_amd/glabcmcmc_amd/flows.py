@@ -213,8 +213,14 @@ class HipAdam:
                                                   C.c_void_p(stream)), "glabc_nf_grad")
         return self.loss, self.grad_blob, self.grad_base
 
-    def step(self, x, chain_major=False):
+    def step(self, x, chain_major=False, group=None, via=None):
+        """group: a torch.distributed process group (or True for the default one) whose ranks share this flow -- the
+        gradient and the loss become the row-weighted means over all ranks' batches before the update (parallel.py)"""
         loss, gb, gq = self.gradient(x, chain_major)
+        if group is not None:
+            from .parallel import average_gradients
+            n_local = x.shape[1] if chain_major else x.reshape(-1, 2).shape[0]
+            average_gradients([gb, gq, loss], n_local, None if group is True else group, via)
         value = float(loss)                                      # one synchronisation per training step (GLMCMC_NFs.py:121)
         if value != value or value in (float("inf"), float("-inf")):
             return value

@@ -372,6 +372,7 @@ class PoolSampler:
         self._hist_ptr, self._hist_row_bytes = self.hist.data_ptr(), self.hist[0].numel() * 4
         self.stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         self._countdown = self.S
+        self.group = None
 
     def load_pool(self, theta_rows, lq):
         """theta_rows (rows, d), lq (rows,): simulate and evaluate the pool (GLMCMC_NFs.py:73-78 / AGLMCMC.py:90-100)"""
@@ -423,6 +424,10 @@ class PoolSampler:
         if self._countdown > 0:
             return False
         used = int(self.kk.max().item())
+        if self.group is not None:                 # ranks sharing one proposal refresh together: the fullest pool decides
+            from .parallel import max_over_ranks
+            g = None if self.group is True else self.group
+            used = max_over_ranks(used, g, self.dev if torch.distributed.get_backend(g) == "nccl" else "cpu")
         if used < self.S:
             self._countdown = self.S - used
             return False
@@ -434,7 +439,7 @@ class PoolSampler:
 
 def run_glmcmc_nf(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, filelocation, global_frequency, step_size,
                   batch_size, base, Train_step, *, num_layers=32, seed=None, device=None, chain0=0, return_device=False,
-                  verbose=True, flow=None, lr=5e-4, weight_decay=1e-5, state_out=None, callback_device="auto"):
+                  verbose=True, flow=None, lr=5e-4, weight_decay=1e-5, state_out=None, callback_device="auto", process_group=None):
     """GLMCMC_NF (GLMCMC_NFs.py:43-186) with the Model as callbacks.  The flow's kernels are the fused path's
     (glabc_nf_sample for the pools, glabc_nf_log_prob_indexed for NF_model.log_prob(Theta_old), HipAdam for the training
     step); the Model is evaluated through its own methods: once per pool on all of its rows (generate_samples, prior_log_prob,
@@ -452,12 +457,16 @@ def run_glmcmc_nf(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, fil
         flow = RealNVP(num_layers, base if isinstance(base, torch.nn.Module) else None)
     flow = flow.to(dev)
     optimizer = HipAdam(flow, lr=lr, weight_decay=weight_decay)                                  # GLMCMC_NFs.py:63
+    ps.group = process_group
+    via = None if process_group is None or torch.distributed.get_backend(None if process_group is True else process_group) == "nccl" \
+        else "cpu"
     count = torch.zeros(1, dtype=torch.int32, device=dev)
     losses = []
 
     def draw_pool(refresh_id):
         flow.eval()
-        z, lq = flow.sample(rows, seed=ps.key ^ 0x9E3779B97F4A7C15, row0=refresh_id * rows)       # :70-72 / 125-127
+        z, lq = flow.sample(rows, seed=ps.key ^ 0x9E3779B97F4A7C15,
+                            row0=(refresh_id << 44) + chains.chain0 * ps.N * ps.S)                # :70-72 / 125-127; per shard
         ps.load_pool(z.contiguous(), lq)
 
     def flow_state():
@@ -486,7 +495,7 @@ def run_glmcmc_nf(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, fil
             if num_train < Train_step:                                                            # :114-124
                 w = ps.pool_weights()
                 idx = resample(w / torch.sum(w), rows)
-                losses.append(optimizer.step(ps.pool["theta"][idx]))
+                losses.append(optimizer.step(ps.pool["theta"][idx], group=process_group, via=via))
                 num_train += 1
                 blob, fdesc = flow_state()
                 log_prob_all()

@@ -7,6 +7,10 @@ sampling.  The only collective is one all-gather (RCCL over xGMI when the backen
 "nccl") of the per-chain streaming sums at checkpoint / ESJD time: per chain
 d + 2*tri(d) float64 words (64 B for d = 2; 4 MiB per GPU at 65 536 chains) --
 latency-bound, one call, no bucketing needed.
+
+The one exception: GLMCMC_NF with ONE flow shared by all chains.  Its weights are replicated; at a training
+step every rank differentiates forward_kld over ITS pool rows and `average_gradients` all-reduces the row-weighted mean
+(0.55 MB for 8 couplings, once per pool refresh at most Train_step times) before the identical Adam update on every rank.
 """
 import torch
 import torch.distributed as dist
@@ -91,3 +95,36 @@ def _diag(d):
         pos.append(k)
         k += d - p
     return pos
+
+
+def average_gradients(tensors, n_local, group=None, via=None):
+    """In place: every tensor (a mean over this rank's n_local rows -- gradient blobs, the loss) becomes the mean over the
+    rows of ALL ranks, sum_r n_r t_r / sum_r n_r: one all-reduce of the concatenated payload.  `via`: device the payload is
+    staged on ("cpu" for a gloo rehearsal of device tensors)."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return tensors
+    flat = torch.cat([t.reshape(-1).double() * float(n_local) for t in tensors] +
+                     [torch.tensor([float(n_local)], dtype=torch.float64, device=tensors[0].device)])
+    home = flat.device
+    if via is not None and torch.device(via) != home:
+        flat = flat.to(via)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat = flat.to(home)
+    total = flat[-1]
+    at = 0
+    for t in tensors:
+        k = t.numel()
+        t.copy_((flat[at:at + k] / total).to(t.dtype).view_as(t))
+        at += k
+    return tensors
+
+
+def max_over_ranks(value, group=None, device=None):
+    """the largest of the ranks' integers (one all-reduce of a single word; `device`: where the word lives -- the GPU for
+    nccl = RCCL, "cpu" for gloo)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())

@@ -290,3 +290,26 @@ def test_glmcmc_nf_with_a_callback_model_has_the_law_of_the_fused_path(hip, kind
     one = g.GLMCMC_NF(user, 30, torch.tensor([0.0, 0.0]), torch.tensor([[1.5, 1.5]]), lp, None, 0.5, 3, 5, None, 2,
                       num_layers=2, seed=2, verbose=False)
     assert one.shape == (30, 2) and one.device.type == "cpu"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fused", "generic"])
+def test_sharded_glmcmc_nf_keeps_one_flow(hip, kind):
+    """chains sharded over two ranks (gloo, both on this GPU) that share the flow: the ranks refresh their pools together,
+    average their gradients (row-weighted) and end with bit-identical flows and the same loss history"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG_PARENT
+    env = dict(os.environ, PYTHONPATH=PKG_PARENT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "nf_sharded.py")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29547" if kind == "fused" else "29548", script, kind],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    rows = sorted([json.loads(l) for l in run.stdout.split("\n") if l.startswith("{")], key=lambda r: r["rank"])
+    assert [r["rank"] for r in rows] == [0, 1] and rows[0]["n"] + rows[1]["n"] == 1000
+    assert rows[0]["flow_sha"] == rows[1]["flow_sha"] and rows[0]["loss"] == rows[1]["loss"]
+    assert rows[0]["num_train"] == rows[1]["num_train"] == 4 and rows[0]["pools"] == rows[1]["pools"]
+    assert all(r["finite"] and 1.0 < r["mean_abs"] < 1.9 for r in rows)

@@ -72,3 +72,40 @@ def test_shard_range_covers_everything():
                 assert a + n == b
             assert spans[-1][0] + spans[-1][1] == n_total
             assert max(s[1] for s in spans) - min(s[1] for s in spans) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glabcmcmc_amd.parallel import average_gradients, max_over_ranks
+        n_local = [100, 300, 50][rank]
+        g = torch.full((4, 5), float(rank + 1))                       # "a mean over this rank's rows"
+        b = torch.tensor([10.0 * (rank + 1), -1.0])
+        loss = torch.tensor([float(rank)])
+        average_gradients([g, b, loss], n_local)
+        q.put((rank, g, b, loss, max_over_ranks([3, 9, 4][rank], None, "cpu")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_weighted_gradient_average_and_refresh_vote():
+    """the shared flow of a sharded GLMCMC_NF: per-rank mean gradients become the mean over all ranks' rows (weights =
+    rows per rank) on every rank; the pool-refresh decision is the maximum over the ranks"""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    w = torch.tensor([100.0, 300.0, 50.0])
+    want_g = float((w * torch.tensor([1.0, 2.0, 3.0])).sum() / w.sum())
+    want_b0 = float((w * torch.tensor([10.0, 20.0, 30.0])).sum() / w.sum())
+    want_loss = float((w * torch.tensor([0.0, 1.0, 2.0])).sum() / w.sum())
+    for r in res:
+        assert torch.allclose(r[1], torch.full((4, 5), want_g)) and abs(float(r[2][0]) - want_b0) < 1e-5
+        assert abs(float(r[2][1]) + 1.0) < 1e-6 and abs(float(r[3]) - want_loss) < 1e-6 and r[4] == 9
