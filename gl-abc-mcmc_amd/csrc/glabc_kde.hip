@@ -126,6 +126,10 @@ struct KdeArgs {
     float* out;
     uint32_t seed_lo, seed_hi;
     int64_t row0;
+    // indexed log_prob (glabc_kde_log_prob_indexed): the points are pts[d*pts_stride + idx[i]], i < *n_dev, results to out[idx[i]]
+    const int32_t* idx;
+    const int32_t* n_dev;
+    int64_t pts_stride;
 };
 
 // inv[d] = 1/bandwidth_d (one IEEE division per wavefront): the reference divides every difference by the bandwidth
@@ -150,12 +154,13 @@ template <int D>
 __global__ void __launch_bounds__(256) kde_log_prob_kernel(const KdeArgs<D> a)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= a.n_points) return;                          // whole wavefront leaves together
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= (a.n_dev ? (int64_t)*a.n_dev : a.n_points)) return;   // whole wavefront leaves together
+    const int64_t p = a.idx ? (int64_t)a.idx[slot] : slot;
     float pt[D], inv[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        pt[d] = a.pts[d * a.n_points + p];
+        pt[d] = a.pts[d * a.pts_stride + p];
         inv[d] = 1.0f / a.bw[d];
     }
     // pass 1: max and NaN flag (torch.logsumexp: amax, kernel_density.py:126)
@@ -297,7 +302,32 @@ __attribute__((visibility("default"))) int glabc_kde_log_prob(const glabc_kde* k
 #define GLABC_CASE(d)                                                              \
     case d: {                                                                      \
         KdeArgs<d> a = kde_pack<d>(kde);                                           \
-        a.pts = pts; a.n_points = n_points; a.out = out;                           \
+        a.pts = pts; a.n_points = n_points; a.out = out; a.pts_stride = n_points;  \
+        hipLaunchKernelGGL((kde_log_prob_kernel<d>), grid, block, 0, s, a);        \
+        break;                                                                     \
+    }
+    switch (kde->dim) { GLABC_CASE(1) GLABC_CASE(2) GLABC_CASE(3) GLABC_CASE(4) }
+#undef GLABC_CASE
+    return launched();
+}
+
+__attribute__((visibility("default"))) int glabc_kde_log_prob_indexed(const glabc_kde* kde, const float* pts, int64_t stride,
+                                                                      const int32_t* idx, const int32_t* n_dev, int64_t max_points,
+                                                                      float* out, void* stream)
+{
+    int rc = kde_check(kde);
+    if (rc) return rc;
+    if (max_points < 0 || max_points > (int64_t)1 << 31 || stride < max_points) return GLABC_ERR_ARG;
+    if (max_points == 0) return GLABC_OK;
+    if (!pts || !out || !idx || !n_dev) return GLABC_ERR_NULL;
+    if (kde->n_samples > (int64_t)1 << 22) return GLABC_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((max_points + 3) / 4)), block(256);       // wavefronts past the device-side count leave at once
+#define GLABC_CASE(d)                                                              \
+    case d: {                                                                      \
+        KdeArgs<d> a = kde_pack<d>(kde);                                           \
+        a.pts = pts; a.n_points = max_points; a.out = out; a.pts_stride = stride;  \
+        a.idx = idx; a.n_dev = n_dev;                                              \
         hipLaunchKernelGGL((kde_log_prob_kernel<d>), grid, block, 0, s, a);        \
         break;                                                                     \
     }

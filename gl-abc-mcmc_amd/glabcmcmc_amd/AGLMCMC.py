@@ -37,7 +37,8 @@ ISIR_STREAM, POOL_STREAM, KDE_STREAM = 0x9E3779B97F4A7C15, 0x5851F42D4C957F2D, 0
 
 def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_ISIR_prop,
             filelocation, global_frequency, step_size, batch_size, alpha, hat_eps_T, device=None, *,
-            seed=None, chain0=0, return_device=False, verbose=True, max_train=None, state_out=None, path="auto", **generic_kw):
+            seed=None, chain0=0, return_device=False, verbose=True, max_train=None, state_out=None, path="auto",
+            check_density_cache=False, **generic_kw):
     if path not in ("auto", "fused", "generic"):
         raise ValueError("path must be 'auto', 'fused' or 'generic'")
     from . import generic
@@ -103,16 +104,29 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
     run = _capi.Run()
     run.seed, run.n_steps, run.global_frequency, run.batch_size, run.hist_stride = key, 1, float(global_frequency), N, n
     hist_ptr, hist_row_bytes = hist.data_ptr(), hist[0].numel() * 4
+    # The proposal density of a chain's current state (:137-140) is a pure function of the state and the proposal: with the
+    # KDE -- an O(centres) sum per chain -- it is kept per chain and re-evaluated only for the chains the step reports as moved
+    # (glabc_kde_log_prob_indexed, list and count on the device) and for all chains after a refit; same values as evaluating
+    # every chain every iteration.
+    moved_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+    n_moved = torch.zeros(2, dtype=torch.int32, device=dev)                                        # counters of odd / even iterations
+    cnt = [n_moved[0:].data_ptr(), n_moved[1:].data_ptr()]
+    kde_current = None                                                                            # the KDE log_q_old was computed with
     for i in range(1, num_ite):
         with torch.cuda.device(dev):
             if KDE is None:                                                                       # :137-140
                 th_rows = chains.theta.t().contiguous()
                 _capi.check(lib.glabc_dist_log_prob(C.byref(isir), th_rows.data_ptr(), n, log_q_old.data_ptr(), stream),
                             "glabc_dist_log_prob")
-            else:
+            elif kde_current is not KDE:
                 log_q_old = KDE.log_prob_soa(chains.theta)
+                kde_current = KDE
+            else:
+                KDE.log_prob_soa_indexed(chains.theta, moved_idx, n_moved[(i + 1) & 1:], log_q_old)   # the previous step's movers
+                if check_density_cache and not torch.equal(log_q_old.view(torch.int32), KDE.log_prob_soa(chains.theta).view(torch.int32)):
+                    raise AssertionError("AGLMCMC: the cached proposal densities differ from a full evaluation at iteration %d" % i)
             pd = _capi.Pool(pool["theta"].data_ptr(), pool["x"].data_ptr(), pool["w"].data_ptr(), log_q_old.data_ptr(),
-                            kk.data_ptr(), int(step_size), 0)
+                            kk.data_ptr(), int(step_size), 0, moved_idx.data_ptr(), cnt[i & 1], cnt[(i + 1) & 1])
             run.step0, run.history = i, hist_ptr + i * hist_row_bytes
             _capi.check(lib.glabc_glmcmc_nf_step(C.byref(model), C.byref(local), C.byref(pd), C.byref(cs), C.byref(run),
                                                  stream), "glabc_glmcmc_nf_step")                 # :125-172, 251-272

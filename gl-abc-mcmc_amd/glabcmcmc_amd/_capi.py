@@ -241,6 +241,8 @@ ENTRY_POINTS = {
     "glabc_kde_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "glabc_kde_log_prob": (C.c_int, [_P(Kde), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "glabc_kde_log_prob_indexed": (C.c_int, [_P(Kde), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_void_p]),
     "glabc_kde_sample": (C.c_int, [_P(Kde), C.c_int64, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_kde_train_weights": (C.c_int, [_P(Model), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_init_weights": (C.c_int, [_P(Model), _P(Dist), _P(Chains), C.c_void_p]),

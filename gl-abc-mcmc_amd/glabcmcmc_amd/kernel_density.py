@@ -102,6 +102,15 @@ class KernelDensity:
                         "glabc_kde_log_prob")
         return out
 
+    def log_prob_soa_indexed(self, pts, idx, n_dev, out):
+        """the same for the points idx[0 .. *n_dev - 1] of pts only (idx, n_dev: int32 device tensors; the count never visits
+        the host), results written to out[idx]; the other entries of `out` are left as they are"""
+        k = self.descriptor()
+        with torch.cuda.device(self.device):
+            _capi.check(_capi.lib().glabc_kde_log_prob_indexed(C.byref(k), pts.data_ptr(), pts.shape[1], idx.data_ptr(), n_dev.data_ptr(),
+                                                               pts.shape[1], out.data_ptr(), self._stream()), "glabc_kde_log_prob_indexed")
+        return out
+
     def log_prob(self, x):
         """x (n_points, n_features) -> (n_points,) log densities -- kernel_density.py:96-128."""
         if not self._fitted:

@@ -489,6 +489,13 @@ typedef struct glabc_kde {
  * wavefront can share one point).  pts is dimension-major [dim][n_points]. */
 int glabc_kde_log_prob(const glabc_kde* kde, const float* pts, int64_t n_points, float* out, void* stream);
 
+/* The same for the points listed in idx[0 .. *n_dev - 1] only: point i = (pts[idx[i]], pts[stride + idx[i]], ...), result to
+ * out[idx[i]].  *n_dev is read on the device (no host synchronisation); max_points bounds it (the grid).  AGLMCMC keeps the
+ * proposal density of every chain's current state (AGLMCMC.py:137-140, a pure function of the state and the fitted KDE) and
+ * refreshes it for the chains that moved. */
+int glabc_kde_log_prob_indexed(const glabc_kde* kde, const float* pts, int64_t stride, const int32_t* idx, const int32_t* n_dev,
+                               int64_t max_points, float* out, void* stream);
+
 /* KernelDensity.sample, kernel_density.py:130-150: row r (global id row0 + r) picks centre j = first index with
  * cum_q[j] > floor(u * cum_q[n-1]), u the float64 uniform of Philox(seed; id, 0, 0) words 0-1 (torch.multinomial
  * with replacement is the same inverse-CDF draw on torch's generator), and adds bandwidth_d * normal_d (normals from

@@ -264,7 +264,8 @@ def test_aglmcmc_end_to_end(hip, tmp_path):
     n = 512
     th0 = torch.zeros(n, 2) + 1.5
     y0 = Model.generate_samples(th0)
-    a = AGLMCMC(Model, 1200, th0, y0, lp, ip, None, 0.6, 30, 5, 0.8, 0.5, seed=4, verbose=False, state_out=st)
+    a = AGLMCMC(Model, 1200, th0, y0, lp, ip, None, 0.6, 30, 5, 0.8, 0.5, seed=4, verbose=False, state_out=st,
+                check_density_cache=True)          # the per-chain proposal-density cache == a full evaluation, every iteration
     b = GLMCMC(Model, 1200, th0, y0, lp, None, 0.6, ip, 5, seed=5, verbose=False)
     assert a.shape == (1200, n, 2)
     pa, pb = a[400:].abs().reshape(-1, 2), b[400:].abs().reshape(-1, 2)
