@@ -542,3 +542,36 @@ def test_hip_graph_replay_walks_the_reference_chains(hip, name):
     same = bits(out.numpy()) == bits(g["chains"][:T + 1])
     assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
     assert (st["chains"].n_moves.cpu().numpy() > 0).any()
+
+
+@pytest.mark.gpu
+def test_hip_theta_dim_beyond_the_descriptor_limit(hip):
+    """theta_dim 12 (> GLABC_MAX_DIM = 8: no glabc_dist can describe the proposals, so they are callbacks as well): GLMCMC
+    and GlobalMCMC run through the split-phase path, chains move, and E theta_j^2 heads for the analytic value of every
+    coordinate (loose: a 12-dimensional random walk mixes slowly; the point is that nothing about the path is dimension-bound)"""
+    from glabcmcmc_amd import GLMCMC, GlobalMCMC, distribution, engine
+    d, n, eps = 12, 4096, 1.0
+    m = TorchMixture(d, eps)
+    lp = distribution.DiagGaussian(d, torch.zeros(d), torch.log(torch.full((d,), 0.25)))
+    ip = distribution.DiagGaussian(d, torch.zeros(d), torch.log(torch.full((d,), 1.0)))
+    g = torch.Generator().manual_seed(1)
+    th0 = 0.8 * (torch.randint(0, 2, (n, d), generator=g).float() * 2 - 1)
+    y0 = th0.abs() + 0.2236 * torch.randn(n, d, generator=g)
+    torch.manual_seed(0)
+    st = {}
+    mom = engine.Moments(n, d, torch.device("cuda", 0))
+    out = GLMCMC(m, 301, th0, y0, lp, None, 0.3, ip, 16, seed=3, stats=mom, verbose=False, state_out=st, return_device=True)
+    assert out.shape == (301, n, d) and torch.isfinite(out).all()
+    assert st["chains"].n_moves.float().mean() > 20                         # the random walk accepts
+    # exact E theta_j^2: |theta_j| is N(mu, s^2) truncated to (0, inf), mu = 1.5/(1+v), s^2 = v/(1+v), v = 0.05 + eps^2 (at
+    # eps = 1 the truncation matters: 1.194, where the untruncated formula of `analytic` gives 1.048)
+    from scipy.stats import norm
+    v = 0.05 + eps ** 2
+    mu, sd = 1.5 / (1 + v), math.sqrt(v / (1 + v))
+    lam = norm.pdf(-mu / sd) / norm.cdf(mu / sd)
+    mean1 = mu + sd * lam
+    want_sq = sd ** 2 * (1 + (-mu / sd) * lam - lam ** 2) + mean1 ** 2
+    late = (out[150:] ** 2).mean(dim=(0, 1)).cpu().numpy()
+    assert np.all(np.abs(late - want_sq) < 0.03 * want_sq), (late, want_sq)
+    out2 = GlobalMCMC(m, 51, th0, y0, ip, None, 0.2, lp, seed=4, verbose=False)
+    assert out2.shape == (51, n, d) and torch.isfinite(out2).all()
