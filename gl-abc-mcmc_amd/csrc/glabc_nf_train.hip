@@ -25,8 +25,9 @@
 //                                                       A = da2 rebuilt from staged a2 (lanes <-> i), B = h1 on the fly
 //                                                       (lanes <-> k); db2 / dW3 are lane-local sums on the way.
 // One LDS image of W2 serves (1) and (2): row stride 129 floats makes both "fixed k, lanes over i" and "fixed i, lanes over k"
-// conflict-free.  LDS: 66 KiB weights + 66 KiB staging + 5 KiB vectors.  Per wave and 32 rows: 3 x 256 MFMAs (the forward
-// pass has 256).  Workgroups write partial sums in the parameter-block layout; one reduction kernel adds them in a fixed
+// conflict-free.  Per wave and 32 rows: 3 x 256 MFMAs (the forward pass has 256).  Two forms: nf_backward_kernel stages a2
+// itself (66 KiB, one wave per SIMD); nf_backward_kernel2 -- the default -- stages only its sign bits (see there), which lets
+// eight waves share a CU.  Workgroups write partial sums in the parameter-block layout; one reduction kernel adds them in a fixed
 // order in double, so a step is reproducible to the bit from run to run.
 //
 // Parity: floating point.  tests/test_nf_train.py holds loss and every gradient to the CPU checker's double-precision
@@ -35,6 +36,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/glabc.h"
@@ -59,7 +61,7 @@ constexpr int B_DLS = B_DSH + BW_ROWS;
 constexpr int B_DZ0 = B_DLS + BW_ROWS;
 constexpr int B_B3 = B_DZ0 + BW_ROWS;
 constexpr int B_FLOATS = B_B3 + 4;
-constexpr int BW_MAX_WGS = 256;                  // one workgroup per CU
+constexpr int BW_MAX_WGS = 256;                  // workgroups per CU-round: one per CU (staged kernel), two (sign-bit kernel)
 
 struct BwArgs {
     const float* block;       // this coupling's parameters
@@ -299,6 +301,318 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
     }
 }
 
+// The same sweep with the batch's a2 NOT staged: phase 2 only needs the SIGN of a2 (d a2 = [a2 > 0] W3^T dp), which is one
+// wave-wide compare per accumulator register (v_cmp -> 64-bit mask = two LDS words), 2 KiB per batch instead of 66 KiB; the
+// one thing that needs a2's magnitude, dW3 += dp (x) relu(a2), is summed over the rows in phase 1 by a reduce-scatter over the
+// 32 lanes of a half (128 values -> 4 per lane in 124 exchanges).  LDS drops to 71 KiB, so TWO workgroups share a CU = two
+// waves per SIMD (the register budget is held to 256 by the launch bounds), and one workgroup's epilogue / butterflies /
+// barriers are covered by the other's MFMAs.
+// (the small arrays first: every one of their reads is then base register + 16-bit immediate; behind the 66 KiB matrix each
+// read needed its own address register -- the round-1 lesson of glabc_nf.hip)
+// WAVES = 4: two workgroups share a CU.  WAVES = 8: one workgroup of eight waves -- a batch is 256 rows, the weights are
+// staged once per CU, and in phase 2 wave w takes hidden units 32 (w & 3) .. for the input units 64 (w >> 2) .. 64 (w >> 2) + 63
+// only: 32 persistent accumulator registers instead of 64, which is what lets the kernel fit 256 registers without scratch.
+template <int WAVES>
+struct BwLds {
+    static constexpr int ROWS = 32 * WAVES;
+    static constexpr int W1 = 0, B1 = W1 + NF_H, B2 = B1 + NF_H, W30 = B2 + NF_H, W31 = W30 + NF_H;
+    static constexpr int Z0 = W31 + NF_H, DSH = Z0 + ROWS, DLS = DSH + ROWS, DZ0 = DLS + ROWS, B3 = DZ0 + ROWS;
+    static constexpr int MASK = B3 + 4;              // uint32 [128 units][WAVES tiles]: bit r = a2[i][row 32 tile + r] > 0
+    static constexpr int W2 = MASK + NF_H * WAVES;   // W2[i][k] at i*WS + k
+    static constexpr int FLOATS = W2 + NF_H * WS;
+};
+static_assert(2 * BwLds<4>::FLOATS * 4 <= 160 * 1024 && BwLds<8>::FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArgs a)
+{
+    using L = BwLds<WAVES>;
+    constexpr int C_W1 = L::W1, C_B1 = L::B1, C_B2 = L::B2, C_W30 = L::W30, C_W31 = L::W31, C_Z0 = L::Z0, C_DSH = L::DSH, C_DLS = L::DLS,
+                  C_DZ0 = L::DZ0, C_B3 = L::B3, C_MASK = L::MASK, C_W2 = L::W2;
+    constexpr int KSPLIT = WAVES / 4;                 // phase 2: waves per 32-unit block of hidden units (each takes 128 / KSPLIT input units)
+    constexpr int NACC = 4 / KSPLIT;                  // ... and so many 32 x 32 accumulators of dW2
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    for (int idx = threadIdx.x; idx < NF_H * NF_H; idx += 64 * WAVES)                      // block holds W2^T [k][i]
+        lds[C_W2 + (idx & (NF_H - 1)) * WS + (idx >> 7)] = a.block[NF_W2_OFF + idx];
+    for (int i = threadIdx.x; i < NF_H; i += 64 * WAVES) {
+        lds[C_W1 + i] = a.block[NF_W1_OFF + i];
+        lds[C_B1 + i] = a.block[NF_B1_OFF + i];
+        lds[C_B2 + i] = a.block[NF_V4_OFF + 4 * i];
+        lds[C_W30 + i] = a.block[NF_V4_OFF + 4 * i + 1];
+        lds[C_W31 + i] = a.block[NF_V4_OFF + 4 * i + 2];
+    }
+    if (threadIdx.x < 2) lds[C_B3 + threadIdx.x] = a.block[NF_B3_OFF + threadIdx.x];
+    __syncthreads();
+
+    const int iblk = wave & 3, kpart = wave >> 2;   // phase 2: this wave's block of hidden units / part of the input units
+    f32x16 gw[NACC];                              // dW2[32 iblk + m][32 (NACC kpart + t) + col], t = 0..NACC-1
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gw[t][r] = 0.0f;
+    float gb2 = 0.0f;                             // neuron 32 wave + col, the rows 2s + half
+    float gw3acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // dW3[col >> 4][unit (col & 15) of tile t, this half], this wave's tiles
+    float gw1a[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gb1a[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // unit 32 t + col, this wave's tiles
+    float gb30 = 0.0f, gb31 = 0.0f;               // this lane's rows
+    float w1c[4], b1c[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        w1c[t] = lds[C_W1 + 32 * t + col];
+        b1c[t] = lds[C_B1 + 32 * t + col];
+    }
+    const float w30i = lds[C_W30 + 32 * iblk + col], w31i = lds[C_W31 + 32 * iblk + col];
+    const float b30 = lds[C_B3], b31 = lds[C_B3 + 1];
+
+    const int64_t wg_row0 = (int64_t)blockIdx.x * a.rows_per_wg;
+    // the rows of a tile are loaded one batch ahead (issued before phase 2, consumed after the next barrier pair)
+    float nz0, nz1p, ng0, ng1p;
+    auto fetch = [&](int64_t first) {
+        const int64_t r = first + 32 * wave + col, rc = r < a.n_rows ? r : a.n_rows - 1;
+        nz0 = a.z[rc];
+        nz1p = a.z[a.n_rows + rc];
+        ng0 = a.g[rc];
+        ng1p = a.g[a.n_rows + rc];
+    };
+    fetch(wg_row0 < a.n_rows ? wg_row0 : 0);
+    for (int64_t row0 = wg_row0; row0 < wg_row0 + a.rows_per_wg && row0 < a.n_rows; row0 += L::ROWS) {
+        // ---------------------------------------------------------------- phase 1: this wave's tile, rows on lanes
+        const int64_t row = row0 + 32 * wave + col;
+        const bool valid = row < a.n_rows;
+        const float z0 = nz0, z1p = nz1p;
+        const float g0 = valid ? ng0 : 0.0f, g1p = valid ? ng1p : 0.0f;
+        const float gl_row = valid ? a.gl : 0.0f;
+        f32x16 a0, a1, a2, a3;                                                                // (1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            a0[r] = lds[C_B2 + i];
+            a1[r] = lds[C_B2 + i + 32];
+            a2[r] = lds[C_B2 + i + 64];
+            a3[r] = lds[C_B2 + i + 96];
+        }
+        {
+            const float* w1 = lds + C_W1 + half;
+            const float* bb1 = lds + C_B1 + half;
+            const float* wi = lds + C_W2 + col * WS + half;                                   // W2[32 t + col][2 s + half]
+#pragma unroll 8
+            for (int s = 0; s < 64; ++s) {
+                const float h1 = __builtin_fmaxf(__builtin_fmaf(w1[2 * s], z0, bb1[2 * s]), 0.0f);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wi[2 * s], h1, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wi[2 * s + 32 * WS], h1, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wi[2 * s + 64 * WS], h1, a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wi[2 * s + 96 * WS], h1, a3, 0, 0, 0);
+            }
+        }
+        float p0 = 0.0f, p1 = 0.0f;
+        uint32_t* mask = reinterpret_cast<uint32_t*>(lds) + C_MASK;
+        auto head = [&](const f32x16& acc, int t) {                  // W3 h2 for this lane's 16 units of tile t; sign bits -> LDS
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i0 = 32 * t + (r & 3) + 8 * (r >> 2);
+                const float h2 = __builtin_fmaxf(acc[r], 0.0f);
+                p0 = __builtin_fmaf(lds[C_W30 + 4 * half + i0], h2, p0);
+                p1 = __builtin_fmaf(lds[C_W31 + 4 * half + i0], h2, p1);
+                const unsigned long long m = __ballot(acc[r] > 0.0f);     // lanes 0..31: unit i0, 32..63: unit i0 + 4; bit = row
+                if (lane == 0) {
+                    mask[i0 * WAVES + wave] = (uint32_t)m;
+                    mask[(i0 + 4) * WAVES + wave] = (uint32_t)(m >> 32);
+                }
+            }
+        };
+        head(a0, 0);
+        head(a1, 1);
+        head(a2, 2);
+        head(a3, 3);
+        const float shift = (p0 + __shfl_xor(p0, 32, 64)) + b30;
+        const float log_s = (p1 + __shfl_xor(p1, 32, 64)) + b31;
+        const float z1 = z1p * glabc_expf_b(log_s) + shift;          // the coupling un-done
+        const float dz1 = g1p * glabc_expf_b(-log_s);
+        const float dsh = -dz1;
+        const float dls = -(g1p * z1p) - gl_row;
+        if (half == 0) {
+            lds[C_Z0 + 32 * wave + col] = z0;
+            lds[C_DSH + 32 * wave + col] = dsh;
+            lds[C_DLS + 32 * wave + col] = dls;
+            gb30 += dsh;
+            gb31 += dls;
+        }
+        {
+            // dW3[c][i] += sum over the tile's rows of relu(a2[i][row]) dp_c[row]: per 32-unit tile t 32 values per lane
+            // (c, r), summed over the 32 lanes of this half by a reduce-scatter -- lane col ends with the total of
+            // (c, r) = (col >> 4, col & 15), one per tile
+            auto rows_sum = [&](const f32x16& acc, int t) {
+                float v[32];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float h2 = __builtin_fmaxf(acc[r], 0.0f);
+                    v[r] = h2 * dsh;
+                    v[16 + r] = h2 * dls;
+                }
+#pragma unroll
+                for (int n = 16, off = 16; n >= 1; n >>= 1, off >>= 1) {
+                    const bool up = (col & off) != 0;
+#pragma unroll
+                    for (int k = 0; k < n; ++k) {
+                        const float keep = up ? v[k + n] : v[k], send = up ? v[k] : v[k + n];
+                        v[k] = keep + __shfl_xor(send, off, 64);
+                    }
+                }
+                gw3acc[t] += v[0];
+            };
+            rows_sum(a0, 0);
+            rows_sum(a1, 1);
+            rows_sum(a2, 2);
+            rows_sum(a3, 3);
+        }
+        // (2) in two passes of two 32-unit output tiles each (32 accumulator registers instead of 64: the kernel has to fit
+        // 256 registers for two waves per SIMD): d_u[r] = dh1 of unit 32 (2 pass + u) + col for the tile's row
+        // m_r = (r&3) + 8(r>>2) + 4 half
+        const float* wk = lds + C_W2 + 4 * half * WS + col;                                   // W2[i0 + 4 half][32 t + col]
+        float part[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] = 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            f32x16 d0, d1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d0[r] = d1[r] = 0.0f;
+            auto back = [&](const f32x16& acc, int t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i0 = 32 * t + (r & 3) + 8 * (r >> 2);
+                    const float dh2 = __builtin_fmaf(lds[C_W30 + 4 * half + i0], dsh, lds[C_W31 + 4 * half + i0] * dls);
+                    const float da2 = acc[r] > 0.0f ? dh2 : 0.0f;
+                    const float* wr = wk + i0 * WS + 64 * pass;
+                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(da2, wr[0], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(da2, wr[32], d1, 0, 0, 0);
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bound the operand prefetch (register budget)
+                }
+            };
+            back(a0, 0);
+            back(a1, 1);
+            back(a2, 2);
+            back(a3, 3);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float zr = __shfl(z0, m, 64);
+                auto unit = [&](float dh1, int t) {
+                    const float da1 = __builtin_fmaf(w1c[t], zr, b1c[t]) > 0.0f ? dh1 : 0.0f;
+                    gw1a[t] = __builtin_fmaf(da1, zr, gw1a[t]);
+                    gb1a[t] += da1;
+                    part[r] = __builtin_fmaf(w1c[t], da1, part[r]);
+                };
+                unit(d0[r], 2 * pass);
+                unit(d1[r], 2 * pass + 1);
+            }
+        }
+        float mine = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float q = part[r];
+            q += __shfl_xor(q, 1, 64);                               // over the 32 lanes of this half (the 128 units)
+            q += __shfl_xor(q, 2, 64);
+            q += __shfl_xor(q, 4, 64);
+            q += __shfl_xor(q, 8, 64);
+            q += __shfl_xor(q, 16, 64);
+            mine = (col == r) ? q : mine;
+        }
+        if (col < 16) lds[C_DZ0 + 32 * wave + (col & 3) + 8 * (col >> 2) + 4 * half] = mine;
+        __syncthreads();
+        if (half == 0 && valid) {
+            a.z[row] = z1;                                           // state before the coupling: (z1, z0)
+            a.z[a.n_rows + row] = z0;
+            a.g[row] = dz1;
+            a.g[a.n_rows + row] = g0 + lds[C_DZ0 + 32 * wave + col];
+        }
+        if (row0 + L::ROWS < wg_row0 + a.rows_per_wg && row0 + L::ROWS < a.n_rows) fetch(row0 + L::ROWS);
+        // ---------------------------------------------------------------- phase 2: neurons 32 wave.., all rows of the batch
+        {
+            const float* zs = lds + C_Z0 + half;
+            const float* ds = lds + C_DSH + half;
+            const float* dl = lds + C_DLS + half;
+            float w1p[NACC], b1p[NACC];                              // this wave's input units 32 (NACC kpart + t) + col
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) {
+                w1p[t] = lds[C_W1 + 32 * (NACC * kpart + t) + col];
+                b1p[t] = lds[C_B1 + 32 * (NACC * kpart + t) + col];
+            }
+            for (int tile = 0; tile < WAVES; ++tile) {               // rows 32 tile .. of the batch: wave `tile`'s sign bits
+                const uint32_t mw = mask[(32 * iblk + col) * WAVES + tile];
+#pragma unroll
+                for (int ss = 0; ss < 16; ++ss) {
+                    const int s = 16 * tile + ss;                    // row 2 s + half = 32 tile + (2 ss + half)
+                    const float dsr = ds[2 * s], dlr = dl[2 * s], zr = zs[2 * s];
+                    const float dh2 = __builtin_fmaf(w30i, dsr, w31i * dlr);
+                    const float da2 = ((mw >> (2 * ss + half)) & 1u) ? dh2 : 0.0f;
+                    gb2 += da2;
+#pragma unroll
+                    for (int t = 0; t < NACC; ++t)
+                        gw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da2, __builtin_fmaxf(__builtin_fmaf(w1p[t], zr, b1p[t]), 0.0f), gw[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                             // the batch's LDS rows / sign bits are free again
+    }
+
+    // ------------------------------------------------------------------------ this workgroup's sums, block layout
+    float* out = a.partial + (int64_t)blockIdx.x * NF_BLOCK_FLOATS;
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * iblk + (r & 3) + 8 * (r >> 2) + 4 * half, kk = 32 * (NACC * kpart + t) + col;
+            out[NF_W2_OFF + kk * NF_H + i] = gw[t][r];
+        }
+    {
+        const float s2 = gb2 + __shfl_xor(gb2, 32, 64);
+        if (half == 0 && kpart == 0) {                               // (the waves of the other input-unit parts saw the same d a2)
+            const int i = 32 * iblk + col;
+            out[NF_V4_OFF + 4 * i] = s2;
+            out[NF_V4_OFF + 4 * i + 3] = 0.0f;
+        }
+    }
+    // dW1 / db1 / db3 / dW3: sums over the waves' tiles, through LDS (the weights are no longer needed) in a fixed order
+    float* sc = lds + C_W2;                      // [wave][256] dW1 | db1, then [wave][64] db3 parts, then [wave][256] dW3
+    constexpr int SC_B3 = 256 * WAVES, SC_W3 = SC_B3 + 64 * WAVES;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = col >> 4, r = col & 15;
+        sc[SC_W3 + wave * 256 + c * 128 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half] = gw3acc[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float sw = gw1a[t] + __shfl_xor(gw1a[t], 32, 64), sb = gb1a[t] + __shfl_xor(gb1a[t], 32, 64);
+        if (half == 0) {
+            sc[wave * 256 + 32 * t + col] = sw;
+            sc[wave * 256 + 128 + 32 * t + col] = sb;
+        }
+    }
+    if (half == 0) {
+        sc[SC_B3 + wave * 64 + col] = gb30;
+        sc[SC_B3 + wave * 64 + 32 + col] = gb31;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int j = threadIdx.x;                                   // 0..127: dW1, 128..255: db1
+        float v = 0.0f, v3 = 0.0f;
+        for (int w = 0; w < WAVES; ++w) {
+            v += sc[w * 256 + j];
+            v3 += sc[SC_W3 + w * 256 + j];
+        }
+        out[(j < 128 ? NF_W1_OFF : NF_B1_OFF - 128) + j] = v;
+        out[NF_V4_OFF + 4 * (j & 127) + 1 + (j >> 7)] = v3;          // dW3[c = j >> 7][i = j & 127]
+    }
+    if (threadIdx.x < 2) {
+        float v = 0.0f;
+        for (int w = 0; w < WAVES; ++w)
+            for (int c = 0; c < 32; ++c) v += sc[SC_B3 + w * 64 + 32 * threadIdx.x + c];
+        out[NF_B3_OFF + threadIdx.x] = v;
+        out[NF_B3_OFF + 2 + threadIdx.x] = 0.0f;
+    }
+}
+
 // Start of the backward sweep.  z = the base-space points (glabc_nf_inverse), lq = log_prob of the rows:
 //   g = dL/dz = gl * d base.log_prob / dz = gl * (-(z - loc) / scale^2)
 //   per-block partial sums (double): sum lq, sum e_j / scale_j, sum (e_j^2 - 1), e = (z - loc) / scale
@@ -392,12 +706,12 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a)
     a.p[j] = p - a.step_size * (m / denom);                                               // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
-static int wgs_for(int64_t n_rows, int* rows_per_wg)
+static int wgs_for(int64_t n_rows, int* rows_per_wg, int max_wgs = 2 * BW_MAX_WGS, int batch_rows = BW_ROWS)
 {
-    const int64_t batches = (n_rows + BW_ROWS - 1) / BW_ROWS;
-    const int64_t wgs = batches < BW_MAX_WGS ? batches : BW_MAX_WGS;
+    const int64_t batches = (n_rows + batch_rows - 1) / batch_rows;
+    const int64_t wgs = batches < max_wgs ? batches : max_wgs;
     const int64_t per = (batches + wgs - 1) / wgs;
-    *rows_per_wg = (int)(per * BW_ROWS);
+    *rows_per_wg = (int)(per * batch_rows);
     return (int)((batches + per - 1) / per);
 }
 
@@ -467,14 +781,19 @@ __attribute__((visibility("default"))) int glabc_nf_grad(const glabc_flow* flow,
     }
     b.gl = (float)gl;
     hipLaunchKernelGGL(nf_base_grad_kernel, dim3(BASE_BLOCKS), dim3(256), 0, s, b);
-    static bool lds_ok = false;
-    if (!lds_ok) {
-        if (hipFuncSetAttribute((const void*)nf_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B_FLOATS * 4) != hipSuccess)
-            return GLABC_ERR_LAUNCH;
-        lds_ok = true;
+    // kernel variants: 8 = sign-bit kernel, one workgroup of eight waves per CU (default); 4 = sign-bit kernel, two workgroups of
+    // four waves per CU; 1 = the staged kernel (GLABC_NF_BW = 8 | 4 | 1, a measuring knob: same results up to summation order)
+    static int variant = 0;
+    if (!variant) {
+        const char* e = std::getenv("GLABC_NF_BW");
+        const int want = (e && e[0] == '1') ? 1 : (e && e[0] == '4') ? 4 : 8;
+        const void* fn = want == 1 ? (const void*)nf_backward_kernel : want == 4 ? (const void*)nf_backward_kernel2<4> : (const void*)nf_backward_kernel2<8>;
+        const int bytes = (want == 1 ? B_FLOATS : want == 4 ? BwLds<4>::FLOATS : BwLds<8>::FLOATS) * 4;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return GLABC_ERR_LAUNCH;
+        variant = want;
     }
     int rows_per_wg;
-    const int wgs = wgs_for(n_rows, &rows_per_wg);
+    const int wgs = wgs_for(n_rows, &rows_per_wg, variant == 4 ? 2 * BW_MAX_WGS : BW_MAX_WGS, variant == 8 ? 256 : BW_ROWS);
     for (int c = 0; c < flow->n_couplings; ++c) {                     // log_prob applied n-1 .. 0: the sweep back runs 0 .. n-1
         BwArgs a;
         a.block = flow->params + (int64_t)c * NF_BLOCK_FLOATS;
@@ -484,7 +803,12 @@ __attribute__((visibility("default"))) int glabc_nf_grad(const glabc_flow* flow,
         a.n_rows = n_rows;
         a.rows_per_wg = rows_per_wg;
         a.gl = (float)gl;
-        hipLaunchKernelGGL(nf_backward_kernel, dim3(wgs), dim3(64 * BW_WAVES), B_FLOATS * 4, s, a);
+        if (variant == 1)
+            hipLaunchKernelGGL(nf_backward_kernel, dim3(wgs), dim3(64 * BW_WAVES), B_FLOATS * 4, s, a);
+        else if (variant == 4)
+            hipLaunchKernelGGL(nf_backward_kernel2<4>, dim3(wgs), dim3(256), BwLds<4>::FLOATS * 4, s, a);
+        else
+            hipLaunchKernelGGL(nf_backward_kernel2<8>, dim3(wgs), dim3(512), BwLds<8>::FLOATS * 4, s, a);
     }
     ReduceArgs r;
     r.partial = w.partial;
