@@ -225,3 +225,20 @@ def test_hip_training_lowers_the_forward_kl(hip):
     assert last < first - 0.3, (first, last)
     # and the flow that the samplers use has the trained parameters
     assert abs(float(-flow.log_prob(x).mean()) - float(opt.gradient(x)[0])) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["1", "4"])
+def test_hip_gradient_other_kernel_forms(hip, variant):
+    """GLABC_NF_BW selects the form of the backward kernel once per process (8 = default; 4 = the sign-bit kernel as two 4-wave
+    workgroups per CU; 1 = the form that stages a2 itself): the measuring knobs pass the same gradient check, in a child
+    process of their own"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GLABC_NF_BW=variant)
+    here = os.path.abspath(__file__)
+    run = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-k",
+                          "test_hip_gradient_matches_the_checker and (3-4133 or 2-70001)"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert run.returncode == 0 and "2 passed" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
