@@ -67,6 +67,7 @@ struct NfArgs {
     const int32_t* n_dev;
     int64_t in_stride;
     int32_t state_floats_per_wave; // pair mode: 192 floats (2 tiles x 3 x 32) per pair slot of a wave
+    float* trace;                 // inverse only, may be NULL: [n_couplings][n_rows] the conditioner input of every coupling (training)
 };
 
 // (shift, log_s) of one coupling for this lane's two rows (one in tile a, one in tile b), conditioner inputs z0a / z0b;
@@ -294,6 +295,10 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
             if (tile_active) {
                 float sh, ls;
                 coupling_params(lds, INVERSE ? z1 : z0, lane, sh, ls);
+                if (INVERSE && a.trace && lane < 32) {
+                    const int64_t row = wg_row0 + (int64_t)wave * 32 + col;
+                    if (row < n_rows) a.trace[(int64_t)c * a.n_rows + row] = z1;
+                }
                 nf_row_apply<INVERSE>(sh, ls, z0, z1, lq);
             }
         } else {
@@ -302,6 +307,10 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
                 float a0 = s[0], a1 = s[32], al = s[64], b0 = s[96], b1 = s[128], bl = s[160];
                 float sa, la, sb, lb;
                 coupling_params2(lds, INVERSE ? a1 : a0, INVERSE ? b1 : b0, lane, sa, la, sb, lb);
+                if (INVERSE && a.trace) {                              // lane l: row 64 p + l of the pair (tile a | tile b)
+                    const int64_t row = wg_row0 + (int64_t)p * 64 + lane;
+                    if (row < n_rows) a.trace[(int64_t)c * a.n_rows + row] = lane < 32 ? a1 : b1;
+                }
                 nf_row_apply<INVERSE>(sa, la, a0, a1, al);
                 nf_row_apply<INVERSE>(sb, lb, b0, b1, bl);
                 if (lane < 32) {
@@ -436,13 +445,15 @@ __attribute__((visibility("default"))) int glabc_nf_log_prob(const glabc_flow* f
 }
 
 __attribute__((visibility("default"))) int glabc_nf_inverse(const glabc_flow* flow, const float* x, int64_t n_rows, float* z_out,
-                                                            float* log_q, void* stream)
+                                                            float* log_q, float* trace, void* stream)
 {
     int rc = nf_check(flow, x, log_q, n_rows);
     if (rc) return rc;
     if (!x || !z_out) return GLABC_ERR_NULL;
     if (n_rows == 0) return GLABC_OK;
-    return nf_launch<true>(nf_pack(flow, x, z_out, log_q, n_rows, 0, 0), (hipStream_t)stream);
+    NfArgs a = nf_pack(flow, x, z_out, log_q, n_rows, 0, 0);
+    a.trace = trace;
+    return nf_launch<true>(a, (hipStream_t)stream);
 }
 
 __attribute__((visibility("default"))) int glabc_nf_log_prob_indexed(const glabc_flow* flow, const float* theta, int64_t stride,

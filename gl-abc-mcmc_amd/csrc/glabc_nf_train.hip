@@ -3,10 +3,13 @@
 // Reference: GLMCMC_NFs.py:63 builds torch.optim.Adam(NF_model.parameters(), lr=5e-4, weight_decay=1e-5) and, each time a pool
 // is used up (at most Train_step times, :112-124), takes ONE step on loss = NF_model.forward_kld(Train_t) =
 // -mean(NF_model.log_prob(Train_t)) over the systematically resampled pool; autograd does the differentiation there.
-// Here the gradient is written out by hand.  A coupling is invertible and leaves its conditioner input untouched, so
-// nothing has to be stored on the way down: glabc_nf_inverse (glabc_nf.hip) pulls the rows back to the base space, then one
-// launch per coupling -- in the order the flow would push them forward again -- recomputes the coupling's activations from
-// its OUTPUT state, un-does it, and back-propagates.  Per row (z0 = conditioner input, z1' = transformed coordinate, g = dL/d.):
+// Here the gradient is written out by hand.  A coupling leaves its conditioner input untouched and its output is the next
+// coupling's input, so almost nothing has to be stored on the way down: glabc_nf_inverse (glabc_nf.hip) pulls the rows back to
+// the base space and keeps ONE float per row and coupling -- the conditioner input it saw -- and then one launch per coupling,
+// in the order the flow would push the rows forward again, recomputes the coupling's activations from that input and
+// back-propagates.  The recomputed a2 is the downward pass's own fmaf chain on the downward pass's own input, so the sweep
+// opens exactly the ReLU gates the float32 evaluation opened (what autograd would differentiate).
+// Per row (z0 = conditioner input, z1' = transformed coordinate, g = dL/d.):
 //     h1 = relu(W1 z0 + b1);  a2 = W2 h1 + b2;  h2 = relu(a2);  (shift, log_s) = W3 h2 + b3;  z1 = z1' exp(log_s) + shift
 //     d z1 = g1' exp(-log_s);  d shift = -d z1;  d log_s = -g1' z1' - dL/dlog_q          (log_q -= log_s;  dL/dlog_q = -1/n)
 //     d a2 = (a2 > 0) (W3^T dp);     d a1 = (a1 > 0) (W2^T d a2);     d z0 = g0 + W1^T d a1
@@ -71,6 +74,7 @@ struct BwArgs {
     int64_t n_rows;
     int32_t rows_per_wg;      // multiple of BW_ROWS
     float gl;                 // dL/dlog_q of a row = -1/n
+    const float* z0_trace;    // [n]: this coupling's conditioner inputs as the downward pass saw them (exact gates)
 };
 
 __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs a)
@@ -109,7 +113,7 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
     float nz0, nz1p, ng0, ng1p;
     auto fetch = [&](int64_t first) {
         const int64_t r = first + 32 * wave + col, rc = r < a.n_rows ? r : a.n_rows - 1;
-        nz0 = a.z[rc];
+        nz0 = a.z0_trace[rc];                // the downward pass's own float (a.z[rc] holds it only up to a rounding)
         nz1p = a.z[a.n_rows + rc];
         ng0 = a.g[rc];
         ng1p = a.g[a.n_rows + rc];
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
         head(a3, 3);
         const float shift = (p0 + __shfl_xor(p0, 32, 64)) + b30;
         const float log_s = (p1 + __shfl_xor(p1, 32, 64)) + b31;
-        const float z1 = z1p * glabc_expf_b(log_s) + shift;          // the coupling un-done
+        const float z1 = z1p * glabc_expf_b(log_s) + shift;          // the coupling un-done (kept in a.z for inspection only)
         const float dz1 = g1p * glabc_expf_b(-log_s);
         const float dsh = -dz1;
         const float dls = -(g1p * z1p) - gl_row;
@@ -369,7 +373,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
     float nz0, nz1p, ng0, ng1p;
     auto fetch = [&](int64_t first) {
         const int64_t r = first + 32 * wave + col, rc = r < a.n_rows ? r : a.n_rows - 1;
-        nz0 = a.z[rc];
+        nz0 = a.z0_trace[rc];                // the downward pass's own float (a.z[rc] holds it only up to a rounding)
         nz1p = a.z[a.n_rows + rc];
         ng0 = a.g[rc];
         ng1p = a.g[a.n_rows + rc];
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
         head(a3, 3);
         const float shift = (p0 + __shfl_xor(p0, 32, 64)) + b30;
         const float log_s = (p1 + __shfl_xor(p1, 32, 64)) + b31;
-        const float z1 = z1p * glabc_expf_b(log_s) + shift;          // the coupling un-done
+        const float z1 = z1p * glabc_expf_b(log_s) + shift;          // the coupling un-done (kept in a.z for inspection only)
         const float dz1 = g1p * glabc_expf_b(-log_s);
         const float dsh = -dz1;
         const float dls = -(g1p * z1p) - gl_row;
@@ -718,7 +722,7 @@ static int wgs_for(int64_t n_rows, int* rows_per_wg, int max_wgs = 2 * BW_MAX_WG
 constexpr int BASE_BLOCKS = 256;
 
 struct Workspace {
-    float *z, *g, *lq, *partial;
+    float *z, *g, *lq, *trace, *partial;
     double* base_partial;
 };
 
@@ -735,6 +739,7 @@ static int64_t carve(int32_t n_couplings, int64_t n_rows, char* base, Workspace*
     w->z = (float*)take(2 * n_rows * 4);
     w->g = (float*)take(2 * n_rows * 4);
     w->lq = (float*)take(n_rows * 4);
+    w->trace = (float*)take((int64_t)n_couplings * n_rows * 4);
     w->partial = (float*)take((int64_t)n_couplings * wgs * NF_BLOCK_FLOATS * 4);
     w->base_partial = (double*)take(BASE_BLOCKS * 5 * 8);
     return at;
@@ -746,7 +751,7 @@ using namespace glabc;
 
 extern "C" {
 
-int glabc_nf_inverse(const glabc_flow* flow, const float* x, int64_t n_rows, float* z_out, float* log_q, void* stream);
+int glabc_nf_inverse(const glabc_flow* flow, const float* x, int64_t n_rows, float* z_out, float* log_q, float* trace, void* stream);
 
 __attribute__((visibility("default"))) int glabc_nf_grad_workspace(int32_t n_couplings, int64_t n_rows, int64_t* bytes)
 {
@@ -766,7 +771,7 @@ __attribute__((visibility("default"))) int glabc_nf_grad(const glabc_flow* flow,
     Workspace w;
     if (carve(flow->n_couplings, n_rows, (char*)workspace, &w) > workspace_bytes) return GLABC_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rc = glabc_nf_inverse(flow, x, n_rows, w.z, w.lq, stream);                            // rows -> base space, log_prob
+    int rc = glabc_nf_inverse(flow, x, n_rows, w.z, w.lq, w.trace, stream);                   // rows -> base space, log_prob, conditioner inputs
     if (rc) return rc;
     const double gl = -1.0 / (double)n_rows;
     BaseArgs b;
@@ -803,6 +808,7 @@ __attribute__((visibility("default"))) int glabc_nf_grad(const glabc_flow* flow,
         a.n_rows = n_rows;
         a.rows_per_wg = rows_per_wg;
         a.gl = (float)gl;
+        a.z0_trace = w.trace + (int64_t)c * n_rows;
         if (variant == 1)
             hipLaunchKernelGGL(nf_backward_kernel, dim3(wgs), dim3(64 * BW_WAVES), B_FLOATS * 4, s, a);
         else if (variant == 4)

@@ -229,7 +229,7 @@ ENTRY_POINTS = {
     "glabc_nf_log_prob": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_nf_log_prob_indexed": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                             C.c_void_p]),
-    "glabc_nf_inverse": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "glabc_nf_inverse": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "glabc_nf_grad_workspace": (C.c_int, [C.c_int32, C.c_int64, _P(C.c_int64)]),
     "glabc_nf_grad": (C.c_int, [_P(Flow), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),

@@ -250,17 +250,22 @@ int glabc_nf_log_prob(const glabc_flow* flow, const float* x, int64_t n_rows, fl
 int glabc_nf_log_prob_indexed(const glabc_flow* flow, const float* theta, int64_t stride, const int32_t* idx,
                               const int32_t* n_dev, int64_t max_rows, float* log_q, void* stream);
 
-/* NF_model.log_prob(x) AND the base-space point it is evaluated at: z_out[2][n] = x pulled back through every coupling. */
-int glabc_nf_inverse(const glabc_flow* flow, const float* x, int64_t n_rows, float* z_out, float* log_q, void* stream);
+/* NF_model.log_prob(x) AND the base-space point it is evaluated at: z_out[2][n] = x pulled back through every coupling;
+ * trace (may be NULL): [n_couplings][n] the conditioner input every coupling saw on the way (what the training step needs to
+ * open exactly the ReLU gates the forward evaluation opened). */
+int glabc_nf_inverse(const glabc_flow* flow, const float* x, int64_t n_rows, float* z_out, float* log_q, float* trace,
+                     void* stream);
 
 /* ---- the training step of GLMCMC_NFs.py:63,112-124 -----------------------------------------------------------------------
  * loss = NF_model.forward_kld(x) = -mean(NF_model.log_prob(x)) over x[2][n_rows] and its gradient with respect to every
  * parameter, differentiated by hand (the reference lets autograd do it, GLMCMC_NFs.py:120-122): grad_params has the layout
  * of flow->params ([n_couplings][GLABC_NF_COUPLING_FLOATS], padding entries 0), grad_base = d/d(loc0, loc1, log_scale0,
  * log_scale1) of the base distribution, *loss is a device scalar.  workspace: device memory of at least
- * glabc_nf_grad_workspace bytes, contents undefined afterwards.  Floating-point parity (sums over rows run on the matrix
- * cores in float32, reduced over workgroups in a fixed order): reproducible to the bit from run to run, within 2e-4 of each
- * tensor's largest entry of the exact gradient (tests/test_nf_train.py). */
+ * glabc_nf_grad_workspace bytes, contents undefined afterwards.  The derivative is that of the float32 evaluation's active
+ * set: every ReLU gate is opened exactly where glabc_nf_log_prob's arithmetic opened it (the conditioner inputs of the
+ * downward pass are kept, 4 bytes per row and coupling).  Floating-point parity (sums over rows run on the matrix cores in
+ * float32, reduced over workgroups in a fixed order): reproducible to the bit from run to run, within 2e-4 of each tensor's
+ * largest entry of the checker's double-precision sums over the same active set (tests/test_nf_train.py). */
 int glabc_nf_grad_workspace(int32_t n_couplings, int64_t n_rows, int64_t* bytes);
 int glabc_nf_grad(const glabc_flow* flow, const float* x, int64_t n_rows, void* workspace, int64_t workspace_bytes,
                   float* grad_params, float* grad_base, float* loss, void* stream);

@@ -1216,9 +1216,38 @@ ORACLE_API int oracle_nf_log_prob(const glabc_flow* f, const float* x, int64_t n
 /* ---- the training step of GLMCMC_NFs.py:63,112-124: loss = forward_kld(x) = -mean(log_prob(x)), its gradient, Adam --------
  * The reference differentiates with autograd; this is the same derivative written out (chain rule through
  * base.log_prob and, coupling by coupling, through z1' = (z1 - shift(z0)) exp(-log_s(z0)), log_q -= log_s with the
- * MLP 1 -> 128 -> 128 -> 2, ReLU'(x) = [x > 0] as torch has it), evaluated in DOUBLE from the float32 parameters: the
- * exact gradient up to 1e-15, against which the float32 kernels are held with a tolerance (tests/test_nf_train.py; this
- * function itself is checked against torch autograd in float64). grad_params: block layout, doubles -> float at the end. */
+ * MLP 1 -> 128 -> 128 -> 2, ReLU'(x) = [x > 0] as torch has it).
+ * What is differentiated is the FLOAT32 evaluation, as autograd does: the downward pass is oracle_nf_log_prob's arithmetic
+ * (so the loss and every ReLU gate are the float32 ones -- a gate whose pre-activation is within rounding of zero would
+ * otherwise open in one evaluation and not in another, and the gradient jumps there), and the chain rule is then
+ * evaluated in DOUBLE at those float32 states with those gates: the exact gradient of the active set up to 1e-15, against
+ * which the float32 kernels are held with a tolerance (tests/test_nf_train.py; this function itself is checked against torch
+ * autograd in float64 on cases where no gate is near zero). grad_params: block layout, doubles -> float at the end. */
+static void nf_coupling_gates(const float* blk, float z0, unsigned char* gate1, unsigned char* gate2, float* shift, float* log_s)
+{
+    /* nf_coupling_params with the gates kept: gate1[k] = [W1 z0 + b1 > 0], gate2[i] = [a2_i > 0] */
+    float h1[NF_H], part[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    for (int k = 0; k < NF_H; ++k) {
+        const float pre = __builtin_fmaf(blk[NF_W1_OFF + k], z0, blk[NF_B1_OFF + k]);
+        gate1[k] = pre > 0.0f;
+        h1[k] = fmaxf(pre, 0.0f);
+    }
+    for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 4; ++t)
+            for (int r = 0; r < 16; ++r) {
+                int i = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float* v = blk + NF_V4_OFF + 4 * i;
+                float acc = v[0];
+                for (int k = 0; k < NF_H; ++k) acc = __builtin_fmaf(blk[k * NF_H + i], h1[k], acc);
+                gate2[i] = acc > 0.0f;
+                float h2 = fmaxf(acc, 0.0f);
+                part[h][0] = __builtin_fmaf(v[1], h2, part[h][0]);
+                part[h][1] = __builtin_fmaf(v[2], h2, part[h][1]);
+            }
+    *shift = (part[0][0] + part[1][0]) + blk[NF_B3_OFF + 0];
+    *log_s = (part[0][1] + part[1][1]) + blk[NF_B3_OFF + 1];
+}
+
 ORACLE_API int oracle_nf_grad(const glabc_flow* f, const float* x, int64_t n, float* grad_params, float* grad_base, float* loss)
 {
     if (!f || !f->params || !x || !grad_params || !grad_base || !loss) return GLABC_ERR_NULL;
@@ -1232,68 +1261,65 @@ ORACLE_API int oracle_nf_grad(const glabc_flow* f, const float* x, int64_t n, fl
 #pragma omp parallel
     {
         double* mine = (double*)calloc((size_t)total + 5, sizeof(double));
-        double* st = (double*)malloc(sizeof(double) * 2 * (size_t)(nc + 1));
-        if (!mine || !st) {
+        float* st = (float*)malloc(sizeof(float) * 3 * (size_t)nc);                     /* per coupling: t0, z1', (unused) */
+        unsigned char* gates = (unsigned char*)malloc((size_t)nc * 2 * NF_H);
+        if (!mine || !st || !gates) {
 #pragma omp atomic write
             failed = 1;
         } else {
 #pragma omp for schedule(static)
             for (int64_t r = 0; r < n; ++r) {
-                /* down: x -> base space, remembering the state in front of every coupling */
-                double z0 = x[r], z1 = x[n + r], lq = 0.0;
+                /* down, in float32 (oracle_nf_log_prob's arithmetic): the states, the gates, log_prob */
+                float z0 = x[r], z1 = x[n + r], lqf = 0.0f;
                 for (int c = nc - 1; c >= 0; --c) {
                     const float* blk = f->params + (int64_t)c * GLABC_NF_COUPLING_FLOATS;
-                    st[2 * c] = z0;
-                    st[2 * c + 1] = z1;
-                    const double t0 = z1, t1 = z0;
-                    double h1[NF_H], sh = blk[NF_B3_OFF], ls = blk[NF_B3_OFF + 1];
-                    for (int k = 0; k < NF_H; ++k) h1[k] = fmax((double)blk[NF_W1_OFF + k] * t0 + (double)blk[NF_B1_OFF + k], 0.0);
-                    for (int i = 0; i < NF_H; ++i) {
-                        double a2 = blk[NF_V4_OFF + 4 * i];
-                        for (int k = 0; k < NF_H; ++k) a2 += (double)blk[k * NF_H + i] * h1[k];
-                        const double h2 = fmax(a2, 0.0);
-                        sh += (double)blk[NF_V4_OFF + 4 * i + 1] * h2;
-                        ls += (double)blk[NF_V4_OFF + 4 * i + 2] * h2;
-                    }
+                    float t0 = z1, t1 = z0, shift, log_s;
+                    nf_coupling_gates(blk, t0, gates + (size_t)c * 2 * NF_H, gates + (size_t)c * 2 * NF_H + NF_H, &shift, &log_s);
                     z0 = t0;
-                    z1 = (t1 - sh) * exp(-ls);
-                    lq -= ls;
+                    z1 = (t1 - shift) * glabc_expf(-log_s);
+                    lqf = lqf + (-log_s);
+                    st[3 * c] = t0;
+                    st[3 * c + 1] = z1;
                 }
-                const double e0 = (z0 - f->base_loc[0]) / f->base_scale[0], e1 = (z1 - f->base_loc[1]) / f->base_scale[1];
-                lq += (double)f->base_c0 - ((f->base_log_scale[0] + 0.5 * e0 * e0) + (f->base_log_scale[1] + 0.5 * e1 * e1));
-                mine[total] += lq;
+                {
+                    float e0 = (z0 - f->base_loc[0]) / f->base_scale[0], e1 = (z1 - f->base_loc[1]) / f->base_scale[1];
+                    float lp = f->base_c0 - ((f->base_log_scale[0] + 0.5f * (e0 * e0)) + (f->base_log_scale[1] + 0.5f * (e1 * e1)));
+                    mine[total] += (double)(lqf + lp);
+                }
+                const double e0 = ((double)z0 - f->base_loc[0]) / f->base_scale[0], e1 = ((double)z1 - f->base_loc[1]) / f->base_scale[1];
                 mine[total + 1] += gl * (e0 / f->base_scale[0]);
                 mine[total + 2] += gl * (e1 / f->base_scale[1]);
                 mine[total + 3] += gl * (e0 * e0 - 1.0);
                 mine[total + 4] += gl * (e1 * e1 - 1.0);
                 double g0 = gl * (-(e0 / f->base_scale[0])), g1 = gl * (-(e1 / f->base_scale[1]));   /* dL/d(z0, z1) */
-                /* back up: coupling 0 was applied last */
+                /* back up in double at the float32 states, with the float32 gates: coupling 0 was applied last */
                 for (int c = 0; c < nc; ++c) {
                     const float* blk = f->params + (int64_t)c * GLABC_NF_COUPLING_FLOATS;
                     double* gb = mine + (int64_t)c * GLABC_NF_COUPLING_FLOATS;
-                    const double in0 = st[2 * c], in1 = st[2 * c + 1];      /* state in front: conditioner input = in1 */
-                    const double t0 = in1;
-                    double h1[NF_H], a2[NF_H], sh = blk[NF_B3_OFF], ls = blk[NF_B3_OFF + 1];
-                    for (int k = 0; k < NF_H; ++k) h1[k] = fmax((double)blk[NF_W1_OFF + k] * t0 + (double)blk[NF_B1_OFF + k], 0.0);
+                    const unsigned char* gate1 = gates + (size_t)c * 2 * NF_H;
+                    const unsigned char* gate2 = gate1 + NF_H;
+                    const double t0 = st[3 * c], z1p = st[3 * c + 1];
+                    double h1[NF_H], h2[NF_H], ls = blk[NF_B3_OFF + 1];
+                    for (int k = 0; k < NF_H; ++k)
+                        h1[k] = gate1[k] ? (double)blk[NF_W1_OFF + k] * t0 + (double)blk[NF_B1_OFF + k] : 0.0;
                     for (int i = 0; i < NF_H; ++i) {
-                        double s2 = blk[NF_V4_OFF + 4 * i];
-                        for (int k = 0; k < NF_H; ++k) s2 += (double)blk[k * NF_H + i] * h1[k];
-                        a2[i] = s2;
-                        const double h2 = fmax(s2, 0.0);
-                        sh += (double)blk[NF_V4_OFF + 4 * i + 1] * h2;
-                        ls += (double)blk[NF_V4_OFF + 4 * i + 2] * h2;
+                        double s2 = 0.0;
+                        if (gate2[i]) {
+                            s2 = blk[NF_V4_OFF + 4 * i];
+                            for (int k = 0; k < NF_H; ++k) s2 += (double)blk[k * NF_H + i] * h1[k];
+                        }
+                        h2[i] = s2;
+                        ls += (double)blk[NF_V4_OFF + 4 * i + 2] * s2;
                     }
-                    const double z1p = (in0 - sh) * exp(-ls);               /* output (g0 <-> conditioner, g1 <-> z1p) */
                     const double dz1 = g1 * exp(-ls), dsh = -dz1, dls = -(g1 * z1p) - gl;
                     gb[NF_B3_OFF] += dsh;
                     gb[NF_B3_OFF + 1] += dls;
                     double dh1[NF_H];
                     for (int k = 0; k < NF_H; ++k) dh1[k] = 0.0;
                     for (int i = 0; i < NF_H; ++i) {
-                        const double h2 = fmax(a2[i], 0.0);
-                        gb[NF_V4_OFF + 4 * i + 1] += dsh * h2;
-                        gb[NF_V4_OFF + 4 * i + 2] += dls * h2;
-                        if (!(a2[i] > 0.0)) continue;
+                        gb[NF_V4_OFF + 4 * i + 1] += dsh * h2[i];
+                        gb[NF_V4_OFF + 4 * i + 2] += dls * h2[i];
+                        if (!gate2[i]) continue;
                         const double da2 = (double)blk[NF_V4_OFF + 4 * i + 1] * dsh + (double)blk[NF_V4_OFF + 4 * i + 2] * dls;
                         gb[NF_V4_OFF + 4 * i] += da2;
                         for (int k = 0; k < NF_H; ++k) {
@@ -1303,12 +1329,12 @@ ORACLE_API int oracle_nf_grad(const glabc_flow* f, const float* x, int64_t n, fl
                     }
                     double dt0 = g0;
                     for (int k = 0; k < NF_H; ++k) {
-                        if (!(h1[k] > 0.0)) continue;
+                        if (!gate1[k]) continue;
                         gb[NF_W1_OFF + k] += dh1[k] * t0;
                         gb[NF_B1_OFF + k] += dh1[k];
                         dt0 += (double)blk[NF_W1_OFF + k] * dh1[k];
                     }
-                    g0 = dz1;                                               /* dL/d(in0, in1) */
+                    g0 = dz1;                                               /* dL/d(state in front of the coupling) */
                     g1 = dt0;
                 }
             }
@@ -1317,6 +1343,7 @@ ORACLE_API int oracle_nf_grad(const glabc_flow* f, const float* x, int64_t n, fl
         }
         free(mine);
         free(st);
+        free(gates);
     }
     if (!failed) {
         for (int64_t j = 0; j < total; ++j) grad_params[j] = (float)acc[j];

@@ -1,12 +1,13 @@
 """Randomised differential test, gfx950 kernels vs the CPU checker (not collected by pytest; run on the GPU box):
 
-    python tests/fuzz_parity.py [seconds] [seed] [rtc]
+    python tests/fuzz_parity.py [seconds] [seed] [rtc | nfgrad]
 
 Random theta_dim, batch size (every fourth GLMCMC case beyond 16: the wide kernel, up to 1200 proposals), epsilon (1e-4 .. 10), global_frequency, Gaussian / Uniform proposals with random
 parameters, y_obs (also near zero), lanes per chain, iterations per launch, chain id offsets -- GLMCMC and GlobalMCMC
 histories, final states and streaming sums must agree with the oracle bit for bit; every fourth case is GLMALA
 (random tau, num_grad, float64 state, gradients), every eighth the g-and-k Model, every sixteenth a random user simulator
-compiled into the kernel at run time (all of them with a third argument `rtc`).
+compiled into the kernel at run time (all of them with a third argument `rtc`), every sixty-fourth the flow's hand-written
+gradient against the checker's (tolerance; `nfgrad` for only those).
 """
 import ctypes as C
 import os
@@ -274,15 +275,57 @@ def one_case_rtc(rng, oracle, k):
     return ok, desc, int(hc.n_moves.sum())
 
 
+def one_case_nf_grad(rng, oracle, k):
+    """The hand-written backward of the coupling stack (glabc_nf_grad) vs the checker's double-precision gradient: every
+    tensor within 2e-4 of its largest entry, the loss within 2e-6 relative (floating-point tolerance, see tests/test_nf_train.py)."""
+    from glabcmcmc_amd.flows import HipAdam, RealNVP
+    nc = int(rng.integers(1, 7))
+    n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 3000), rng.integers(3000, 12000)]))
+    torch.manual_seed(int(rng.integers(0, 2 ** 31)))
+    flow = RealNVP(nc)
+    with torch.no_grad():
+        for c in flow.couplings:
+            c.l3.weight.normal_(0, float(rng.uniform(0.05, 0.5)) / 128 ** 0.5)
+            c.l3.bias.normal_(0, 0.1)
+            c.l1.bias.normal_(0, float(rng.uniform(0.0, 0.5)))
+            c.l2.bias.normal_(0, 0.1)
+        flow.q0.loc.copy_(torch.tensor([[float(rng.normal(0, 0.3)), float(rng.normal(0, 0.3))]]))
+        flow.q0.log_scale.copy_(torch.tensor([[float(rng.normal(0, 0.2)), float(rng.normal(0, 0.2))]]))
+    blob = flow.packed_params().numpy().copy()
+    f = flow.descriptor(torch.from_numpy(blob))
+    f.params = blob.ctypes.data
+    x = (rng.standard_normal((2, n)) * float(rng.uniform(0.5, 2.0)) + rng.normal(0, 0.5, (2, 1))).astype(np.float32)
+    gp, gb, loss = np.zeros_like(blob), np.zeros(4, np.float32), np.zeros(1, np.float32)
+    assert oracle.oracle_nf_grad(C.byref(f), x.ctypes.data, n, gp.ctypes.data, gb.ctypes.data, loss.ctypes.data) == 0
+    opt = HipAdam(flow.cuda())
+    lh, gph, gbh = opt.gradient(torch.from_numpy(x).cuda(), chain_major=True)
+    torch.cuda.synchronize()
+    gph, gbh, lh = gph.cpu().numpy(), gbh.cpu().numpy(), float(lh)
+    H = 128
+    ok = abs(lh - float(loss[0])) <= 2e-6 * abs(float(loss[0])) + 1e-7 and np.allclose(gbh, gb, rtol=2e-4, atol=2e-6)
+    v4g, v4h = gp[:, H * H + 2 * H:H * H + 6 * H].reshape(nc, H, 4), gph[:, H * H + 2 * H:H * H + 6 * H].reshape(nc, H, 4)
+    worst = 0.0
+    for a, b in ((gp[:, :H * H], gph[:, :H * H]), (gp[:, H * H:H * H + H], gph[:, H * H:H * H + H]),
+                 (gp[:, H * H + H:H * H + 2 * H], gph[:, H * H + H:H * H + 2 * H]), (v4g[:, :, 0], v4h[:, :, 0]),
+                 (v4g[:, :, 1:3], v4h[:, :, 1:3]), (gp[:, H * H + 6 * H:H * H + 6 * H + 2], gph[:, H * H + 6 * H:H * H + 6 * H + 2])):
+        scale = np.abs(a).max()
+        ok = ok and bool(np.isfinite(b).all())
+        worst = max(worst, float(np.abs(a - b).max() / (scale + 1e-30)))
+    ok = ok and worst <= 2e-4         # (both sides open the ReLU gates of the float32 evaluation: no jumps at the kinks)
+    return ok, dict(case=k, algo="nf-grad", couplings=nc, rows=n, loss=float(loss[0]), worst=worst), 0
+
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     oracle = oracle_lib.load()
     _capi.lib()
     RTC_ONLY = len(sys.argv) > 3 and sys.argv[3] == "rtc"
+    NF_ONLY = len(sys.argv) > 3 and sys.argv[3] == "nfgrad"
     t0, k, moves, bad = time.time(), 0, 0, []
     while time.time() - t0 < budget:
-        fn = one_case_rtc if (RTC_ONLY or k % 16 == 6) else one_case_mala if k % 4 == 3 else one_case_gk if k % 8 == 5 else \
+        fn = one_case_nf_grad if (NF_ONLY or k % 64 == 17) else one_case_rtc if (RTC_ONLY or k % 16 == 6) else one_case_mala if k % 4 == 3 else one_case_gk if k % 8 == 5 else \
             one_case_nf if k % 32 == 9 else one_case
         ok, desc, mv = fn(rng, oracle, k)
         moves += mv

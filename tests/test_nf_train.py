@@ -1,8 +1,9 @@
 """The training step of GLMCMC_NF's flow (GLMCMC_NFs.py:63,112-124: loss = forward_kld = -mean(log_prob), Adam with L2 weight
 decay).  The reference differentiates with autograd; the build has a hand-written backward on the matrix cores.
 
-CPU: the checker's double-precision gradient (oracle_nf_grad) against torch autograd in float64 of the same model;
-     oracle_adam_step against torch.optim.Adam.
+CPU: the checker's gradient (oracle_nf_grad: the float32 evaluation's states and ReLU gates, the chain rule in double) against
+     torch autograd in float64 of the same model (cases without a pre-activation within rounding of zero); oracle_adam_step
+     against torch.optim.Adam.
 GPU: glabc_nf_grad against the checker (floating-point tolerance: every gradient tensor within 2e-4 of its largest entry,
      the loss within 2e-6 relative -- float32 matrix-core sums over the rows against exact sums) and against float32 torch
      autograd on the device; bit-reproducibility from run to run; glabc_adam_step == checker bit for bit; whole training
