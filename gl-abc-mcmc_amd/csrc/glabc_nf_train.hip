@@ -7,7 +7,7 @@
 // coupling's input, so almost nothing has to be stored on the way down: glabc_nf_inverse (glabc_nf.hip) pulls the rows back to
 // the base space and keeps ONE float per row and coupling -- the conditioner input it saw -- and then one launch per coupling,
 // in the order the flow would push the rows forward again, recomputes the coupling's activations from that input and
-// back-propagates.  The recomputed a2 is the downward pass's own fmaf chain on the downward pass's own input, so the sweep
+// back-propagates (its transformed coordinate z1' is the NEXT coupling's kept input, so no coupling has to be un-done).  The recomputed a2 is the downward pass's own fmaf chain on the downward pass's own input, so the sweep
 // opens exactly the ReLU gates the float32 evaluation opened (what autograd would differentiate).
 // Per row (z0 = conditioner input, z1' = transformed coordinate, g = dL/d.):
 //     h1 = relu(W1 z0 + b1);  a2 = W2 h1 + b2;  h2 = relu(a2);  (shift, log_s) = W3 h2 + b3;  z1 = z1' exp(log_s) + shift
@@ -68,8 +68,9 @@ constexpr int BW_MAX_WGS = 256;                  // workgroups per CU-round: one
 
 struct BwArgs {
     const float* block;       // this coupling's parameters
-    float* z;                 // [2][n]: in = state after this coupling in the log_prob direction, out = the state before it
-    float* g;                 // [2][n]: dL/dstate, same convention
+    const float* z1p;         // [n]: the transformed coordinate this coupling put out on the way down (= the next coupling's
+                              //      conditioner input; the base-space point's second coordinate for coupling 0)
+    float* g;                 // [2][n]: in = dL/d(state after this coupling in the log_prob direction), out = dL/d(state before it)
     float* partial;           // [gridDim.x][NF_BLOCK_FLOATS] gradient sums of this coupling, one block per workgroup
     int64_t n_rows;
     int32_t rows_per_wg;      // multiple of BW_ROWS
@@ -106,15 +107,15 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
         b1c[t] = lds[B_B1 + 32 * t + col];
     }
     const float w30i = lds[B_W30 + 32 * wave + col], w31i = lds[B_W31 + 32 * wave + col];
-    const float b30 = lds[B_B3], b31 = lds[B_B3 + 1];
+    const float b31 = lds[B_B3 + 1];
 
     const int64_t wg_row0 = (int64_t)blockIdx.x * a.rows_per_wg;
     // the rows of a tile are loaded one batch ahead (issued before phase 2, consumed after the next barrier pair)
     float nz0, nz1p, ng0, ng1p;
     auto fetch = [&](int64_t first) {
         const int64_t r = first + 32 * wave + col, rc = r < a.n_rows ? r : a.n_rows - 1;
-        nz0 = a.z0_trace[rc];                // the downward pass's own float (a.z[rc] holds it only up to a rounding)
-        nz1p = a.z[a.n_rows + rc];
+        nz0 = a.z0_trace[rc];
+        nz1p = a.z1p[rc];
         ng0 = a.g[rc];
         ng1p = a.g[a.n_rows + rc];
     };
@@ -148,14 +149,13 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
                 a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wi[2 * s + 96 * WS], h1, a3, 0, 0, 0);
             }
         }
-        float p0 = 0.0f, p1 = 0.0f;
+        float p1 = 0.0f;                                             // log_s = W3[1] h2 + b3[1] (the shift is not needed going back)
         float* srow = lds + B_S + (32 * wave + col) * WS + 4 * half;
         auto head = [&](const f32x16& acc, int t) {                  // W3 h2 for this lane's 16 units of tile t; a2 -> staging
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i0 = 32 * t + (r & 3) + 8 * (r >> 2);
                 const float h2 = __builtin_fmaxf(acc[r], 0.0f);
-                p0 = __builtin_fmaf(lds[B_W30 + 4 * half + i0], h2, p0);
                 p1 = __builtin_fmaf(lds[B_W31 + 4 * half + i0], h2, p1);
                 srow[i0] = acc[r];
             }
@@ -164,9 +164,7 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
         head(a1, 1);
         head(a2, 2);
         head(a3, 3);
-        const float shift = (p0 + __shfl_xor(p0, 32, 64)) + b30;
         const float log_s = (p1 + __shfl_xor(p1, 32, 64)) + b31;
-        const float z1 = z1p * glabc_expf_b(log_s) + shift;          // the coupling un-done (kept in a.z for inspection only)
         const float dz1 = g1p * glabc_expf_b(-log_s);
         const float dsh = -dz1;
         const float dls = -(g1p * z1p) - gl_row;
@@ -225,9 +223,7 @@ __global__ void __launch_bounds__(64 * BW_WAVES) nf_backward_kernel(const BwArgs
         if (col < 16) lds[B_DZ0 + 32 * wave + (col & 3) + 8 * (col >> 2) + 4 * half] = mine;
         __syncthreads();
         if (half == 0 && valid) {
-            a.z[row] = z1;                                           // state before the coupling: (z1, z0)
-            a.z[a.n_rows + row] = z0;
-            a.g[row] = dz1;
+            a.g[row] = dz1;                                          // state before the coupling: (z1, z0)
             a.g[a.n_rows + row] = g0 + lds[B_DZ0 + 32 * wave + col];
         }
         if (row0 + BW_ROWS < wg_row0 + a.rows_per_wg && row0 + BW_ROWS < a.n_rows) fetch(row0 + BW_ROWS);
@@ -366,15 +362,15 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
         b1c[t] = lds[C_B1 + 32 * t + col];
     }
     const float w30i = lds[C_W30 + 32 * iblk + col], w31i = lds[C_W31 + 32 * iblk + col];
-    const float b30 = lds[C_B3], b31 = lds[C_B3 + 1];
+    const float b31 = lds[C_B3 + 1];
 
     const int64_t wg_row0 = (int64_t)blockIdx.x * a.rows_per_wg;
     // the rows of a tile are loaded one batch ahead (issued before phase 2, consumed after the next barrier pair)
     float nz0, nz1p, ng0, ng1p;
     auto fetch = [&](int64_t first) {
         const int64_t r = first + 32 * wave + col, rc = r < a.n_rows ? r : a.n_rows - 1;
-        nz0 = a.z0_trace[rc];                // the downward pass's own float (a.z[rc] holds it only up to a rounding)
-        nz1p = a.z[a.n_rows + rc];
+        nz0 = a.z0_trace[rc];
+        nz1p = a.z1p[rc];
         ng0 = a.g[rc];
         ng1p = a.g[a.n_rows + rc];
     };
@@ -408,14 +404,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
                 a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wi[2 * s + 96 * WS], h1, a3, 0, 0, 0);
             }
         }
-        float p0 = 0.0f, p1 = 0.0f;
+        float p1 = 0.0f;                                             // log_s = W3[1] h2 + b3[1] (the shift is not needed going back)
         uint32_t* mask = reinterpret_cast<uint32_t*>(lds) + C_MASK;
         auto head = [&](const f32x16& acc, int t) {                  // W3 h2 for this lane's 16 units of tile t; sign bits -> LDS
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i0 = 32 * t + (r & 3) + 8 * (r >> 2);
                 const float h2 = __builtin_fmaxf(acc[r], 0.0f);
-                p0 = __builtin_fmaf(lds[C_W30 + 4 * half + i0], h2, p0);
                 p1 = __builtin_fmaf(lds[C_W31 + 4 * half + i0], h2, p1);
                 const unsigned long long m = __ballot(acc[r] > 0.0f);     // lanes 0..31: unit i0, 32..63: unit i0 + 4; bit = row
                 if (lane == 0) {
@@ -428,9 +423,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
         head(a1, 1);
         head(a2, 2);
         head(a3, 3);
-        const float shift = (p0 + __shfl_xor(p0, 32, 64)) + b30;
         const float log_s = (p1 + __shfl_xor(p1, 32, 64)) + b31;
-        const float z1 = z1p * glabc_expf_b(log_s) + shift;          // the coupling un-done (kept in a.z for inspection only)
         const float dz1 = g1p * glabc_expf_b(-log_s);
         const float dsh = -dz1;
         const float dls = -(g1p * z1p) - gl_row;
@@ -525,9 +518,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
         if (col < 16) lds[C_DZ0 + 32 * wave + (col & 3) + 8 * (col >> 2) + 4 * half] = mine;
         __syncthreads();
         if (half == 0 && valid) {
-            a.z[row] = z1;                                           // state before the coupling: (z1, z0)
-            a.z[a.n_rows + row] = z0;
-            a.g[row] = dz1;
+            a.g[row] = dz1;                                          // state before the coupling: (z1, z0)
             a.g[a.n_rows + row] = g0 + lds[C_DZ0 + 32 * wave + col];
         }
         if (row0 + L::ROWS < wg_row0 + a.rows_per_wg && row0 + L::ROWS < a.n_rows) fetch(row0 + L::ROWS);
@@ -802,7 +793,7 @@ __attribute__((visibility("default"))) int glabc_nf_grad(const glabc_flow* flow,
     for (int c = 0; c < flow->n_couplings; ++c) {                     // log_prob applied n-1 .. 0: the sweep back runs 0 .. n-1
         BwArgs a;
         a.block = flow->params + (int64_t)c * NF_BLOCK_FLOATS;
-        a.z = w.z;
+        a.z1p = c == 0 ? w.z + n_rows : w.trace + (int64_t)(c - 1) * n_rows;
         a.g = w.g;
         a.partial = w.partial + (int64_t)c * wgs * NF_BLOCK_FLOATS;
         a.n_rows = n_rows;
