@@ -198,10 +198,8 @@ class HipAdam:
         xx = (xx if chain_major else xx.reshape(-1, 2).t()).contiguous()
         n = xx.shape[1]
         f = flow.descriptor(self.blob)
-        f.base_loc[0], f.base_loc[1] = float(self.base[0]), float(self.base[1])
-        f.base_log_scale[0], f.base_log_scale[1] = float(self.base[2]), float(self.base[3])
-        sc = torch.exp(self.base[2:4]).cpu()
-        f.base_scale[0], f.base_scale[1] = float(sc[0]), float(sc[1])
+        b = torch.cat([self.base, torch.exp(self.base[2:4])]).tolist()        # loc0, loc1, log_scale0, log_scale1, scale0, scale1
+        f.base_loc[0], f.base_loc[1], f.base_log_scale[0], f.base_log_scale[1], f.base_scale[0], f.base_scale[1] = b
         need = C.c_int64()
         _capi.check(_capi.lib().glabc_nf_grad_workspace(f.n_couplings, n, C.byref(need)), "glabc_nf_grad_workspace")
         if self._ws is None or self._ws.numel() < need.value:

@@ -522,6 +522,20 @@ def run_aglmcmc(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initi
     if not hasattr(ABCset, "discrepancy"):
         raise TypeError("AGLMCMC needs Model.discrepancy (AGLMCMC.py:93)")
     isir = ProposalCallbacks(Initial_ISIR_prop, dev)
+    isir_desc = dist_descriptor(Initial_ISIR_prop, d)
+    drawn = [0]
+
+    def isir_forward():
+        """Initial_ISIR_prop.forward(rows): on the device from the Philox stream when the proposal has a descriptor"""
+        if isir_desc is None:
+            return isir.forward(rows)
+        z = torch.empty(d, rows, dtype=torch.float32, device=dev)
+        lq = torch.empty(rows, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _capi.check(ps.lib.glabc_dist_forward(C.byref(isir_desc), rows, ps.key ^ 0x9E3779B97F4A7C15, (drawn[0] << 44) +
+                                                  chains.chain0 * ps.N * ps.S, z.data_ptr(), lq.data_ptr(), ps.stream), "glabc_dist_forward")
+        drawn[0] += 1
+        return z.t().contiguous(), lq
 
     def discrepancy(y):
         return model._call(lambda cuda: model._back(ABCset.discrepancy(y if cuda else y.cpu()), y.shape[0])).view(-1)
@@ -536,7 +550,7 @@ def run_aglmcmc(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initi
         pool = ps.load_pool(theta_rows, lq)
         pool["dis"] = discrepancy(pool["x"])                                                      # :93 / 236
 
-    th, lq = isir.forward(rows)                                                                   # :80-81
+    th, lq = isir_forward()                                                                       # :80-81
     load(th, lq)
     KDE, kde_rows, warned = None, 0, False
     num_train, eps_num, hat_eps = 0, 0, 1000000.0                                                 # :119
@@ -574,7 +588,7 @@ def run_aglmcmc(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initi
                 KDE.fit(pool["theta"][:m][keep], tw[:m][keep])                                    # :211-215
                 num_train += 1
             if KDE is None:                                                                       # no usable weights yet
-                th, lq = isir.forward(rows)
+                th, lq = isir_forward()
                 load(th, lq)
                 continue
             got, parts = 0, []
