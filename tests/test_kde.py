@@ -329,3 +329,42 @@ def test_aglmcmc_with_a_callback_model(hip, tmp_path):
     pa, pb = a[400:].abs().reshape(-1, 2), b[400:].abs().reshape(-1, 2)
     assert torch.allclose(pa.mean(0), pb.mean(0), atol=0.03), (pa.mean(0), pb.mean(0))
     assert torch.allclose(pa.std(0), pb.std(0), atol=0.03), (pa.std(0), pb.std(0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n", [(2, 8192), (2, 5000), (1, 8192), (3, 3000)])
+def test_hip_kde_log_prob_at_aglmcmc_size_equals_oracle(hip, oracle, d, n):
+    """KDEs of AGLMCMC's size (up to 8192 centres) against the checker, bit for bit -- zero-weight centres, far tails and NaN
+    points included -- also through the indexed entry point (listed points only, count on the device, the rest untouched)."""
+    rng = np.random.default_rng(n + d)
+    X = (rng.standard_normal((n, d)) * 1.5).astype(np.float32)
+    w = rng.random(n).astype(np.float32)
+    w[rng.random(n) < 0.1] = 0.0
+    xs, weights, log_w, wq, consts = oracle_fit(oracle, X, w, rule("silverman", n, d), None)
+    k = kde_struct(xs, log_w, None, consts, d, n)
+    pts = (rng.standard_normal((1500, d)) * 2.5).astype(np.float32)
+    pts[7] = 60.0                                                       # far tail
+    pts[11, 0] = np.nan
+    ps = np.ascontiguousarray(pts.T)
+    ref = np.empty(len(pts), np.float32)
+    assert oracle.oracle_kde_log_prob(C.byref(k), ps.ctypes.data, len(pts), ref.ctypes.data) == 0
+    xg, lg = torch.from_numpy(xs).cuda(), torch.from_numpy(log_w).cuda()
+    kg = A.Kde()
+    C.memmove(C.byref(kg), C.byref(k), C.sizeof(k))
+    kg.x, kg.log_w, kg.cum_q = xg.data_ptr(), lg.data_ptr(), None
+    pg, og = torch.from_numpy(ps).cuda(), torch.empty(len(pts), device="cuda")
+    assert hip.glabc_kde_log_prob(C.byref(kg), pg.data_ptr(), len(pts), og.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(og.cpu().numpy()), bits(ref))
+    # indexed: a third of the points, in a shuffled order, count on the device
+    idx = torch.from_numpy(rng.permutation(len(pts))[:700].astype(np.int32)).cuda()
+    cnt = torch.tensor([700], dtype=torch.int32, device="cuda")
+    out = torch.full((len(pts),), -7.0, device="cuda")
+    assert hip.glabc_kde_log_prob_indexed(C.byref(kg), pg.data_ptr(), len(pts), idx.data_ptr(), cnt.data_ptr(), len(pts),
+                                          out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    sel = idx.cpu().numpy()
+    assert np.array_equal(bits(got[sel]), bits(ref[sel]))
+    rest = np.setdiff1d(np.arange(len(pts)), sel)
+    assert (got[rest] == -7.0).all()
