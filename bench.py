@@ -749,7 +749,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         out = {
-            "metric": "MH accept-steps/sec (whole node), 65 536 chains, Mixture_set dim=2",
+            "metric": "MH accept-steps/sec (whole node) + ESJD, 65 536 chains, Mixture_set dim=2",
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
