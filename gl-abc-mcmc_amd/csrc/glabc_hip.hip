@@ -554,7 +554,8 @@ __attribute__((target("fma"))) static bool reciprocal_division_exact(float s, fl
     return true;
 }
 
-static float verified_reciprocal(float s)
+namespace glabc {
+float verified_reciprocal(float s)
 {
     if (!(s >= 0x1p-20f && s <= 0x1p20f) || !__builtin_cpu_supports("fma")) return 0.0f;
     static std::mutex lock;
@@ -571,6 +572,7 @@ static float verified_reciprocal(float s)
     if (n_seen < 16) ++n_seen;
     return out;
 }
+}  // namespace glabc
 
 template <int D, int YD = D>
 static StepArgs<D, YD> pack_args(const glabc_model* m, const glabc_dist* local, const glabc_dist* global,

@@ -26,8 +26,21 @@ inline DistArgs<D> pack_dist(const glabc_dist* g)
     return o;
 }
 
-// kern_rinv: RN(1/kern_scale) when the caller has verified the three-instruction division of model_log_kernel for this divisor
-// (glabc_hip.hip verified_reciprocal), else 0
+// RN(1/s) if the three-instruction division of model_log_kernel (IEEE mul + two fused multiply-adds) equals the IEEE quotient for
+// EVERY float32 dividend with this divisor -- checked exhaustively on the host, ~7 ms, remembered per divisor -- else 0
+// (glabc_hip.hip)
+float verified_reciprocal(float s);
+
+// the all-DiagGaussian, unit-scale prior / global configuration (the reference example's) gets the branch-free kernel variant
+// VAR_GAUSS_UNIT (same results bit for bit: tests/test_hip_parity.py::test_unit_gaussian_variant_and_its_fallback)
+template <int D, int YD>
+inline bool gauss_unit_config(const StepArgs<D, YD>& a)
+{
+    return YD == D && a.prior.kind == GLABC_DIST_DIAG_GAUSS && a.prior.unit_scale && a.global.kind == GLABC_DIST_DIAG_GAUSS &&
+           a.global.unit_scale && a.local.kind == GLABC_DIST_DIAG_GAUSS && a.y_obs_away != 0 && a.kern_rinv != 0.0f;
+}
+
+// kern_rinv: verified_reciprocal(kern_scale) or 0
 template <int D, int YD = D>
 inline StepArgs<D, YD> pack_args_rinv(const glabc_model* m, const glabc_dist* local, const glabc_dist* global,
                                       const glabc_chains* c, const glabc_run* r, float kern_rinv)

@@ -18,6 +18,12 @@ namespace glabc {
 
 template __global__ void sampler_kernel<GLABC_RTC_ALGO, GLABC_RTC_D, GLABC_RTC_YD, GLABC_RTC_N, GLABC_RTC_L, VAR_GENERIC, 0>(
     const StepArgs<GLABC_RTC_D, GLABC_RTC_YD>);
+#if GLABC_RTC_YD == GLABC_RTC_D
+// ... and the branch-free variant for unit-scale Gaussian prior / global proposal (chosen per launch by the host, as for the
+// built-in kernels: glabc_pack.h gauss_unit_config)
+template __global__ void sampler_kernel<GLABC_RTC_ALGO, GLABC_RTC_D, GLABC_RTC_YD, GLABC_RTC_N, GLABC_RTC_L, VAR_GAUSS_UNIT, 0>(
+    const StepArgs<GLABC_RTC_D, GLABC_RTC_YD>);
+#endif
 
 // generate_samples(theta, 1) on rows with the noise supplied (the Model protocol's callback, for y0 and the split-phase path):
 // theta[n][D], eps[n][ND] -> y[n][YD]
