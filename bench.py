@@ -481,7 +481,7 @@ def bench_callback(args):
         st.clear()
         GLMCMC(model, K + 1, state["theta"], state["y"], lp, None, GF, ip, N, seed=20261003 + step_idx[0], record_history=False,
                stats=mom, verbose=False, state_out=st, sentinel_redraw=not args.no_sentinel,
-               graph="auto" if args.no_sentinel and not args.no_graph else False)
+               graph=False if args.no_graph else "auto")
         ch = st["chains"]
         state["theta"], state["y"] = ch.theta.t(), ch.y.t()            # stay on the device (prepare() copies through the host)
         step_idx[0] += 1

@@ -163,7 +163,8 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     graph: 'auto' | True | False.  An iteration whose work never visits the host -- descriptor proposals, callbacks on CUDA
     tensors, no sentinel check (GlobalMCMC, or sentinel_redraw=False) -- is captured ONCE as a hipGraph (torch.cuda.graph:
     the two HIP kernels with the iteration index in device memory, glabc_run.step0_device, plus the Model's own kernels) and
-    replayed; 'auto' falls back to launching eagerly when the capture is not possible (e.g. a callback that synchronises)."""
+    replayed; 'auto' falls back to launching eagerly when the capture is not possible (e.g. a callback that synchronises).
+    With the sentinel check on (GLMCMC's default) the replay is speculative, see below: same results as the eager loop."""
     lib = _capi.lib()
     dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
     n, d, yd = chains.n, chains.d, chains.yd
@@ -212,6 +213,7 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     gp = C.byref(global_desc) if global_desc is not None else None
 
     keep = {}                                              # tensors whose addresses the current StepIO holds
+    speculating = [False]                                  # inside a captured iteration: count sentinel hits instead of redrawing
 
     def iteration(i):
         """one iteration on torch's current stream; i = None: the index is read from step_t on the device (graph)"""
@@ -235,7 +237,13 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
                 theta_prop[:n] = torch.where(glob_rows.view(-1, 1), theta_prop[:n], row0_local)
         prior_prop = model.prior(theta_prop)                           # GLMCMC.py:74,92,96
         io.prior_prop = prior_prop.data_ptr()
-        if sentinel_redraw and algo == _capi.ALGO_GLMCMC:              # GLMCMC.py:92-93
+        if sentinel_redraw and algo == _capi.ALGO_GLMCMC and speculating[0]:
+            # captured form: the redraw loop needs the host, so local candidates that hit the sentinel are only COUNTED (one
+            # launch of the redraw kernel: its device counter is never zeroed here), and the replay loop below rolls the segment
+            # back and redoes it eagerly if the count is ever non-zero
+            _capi.check(lib.glabc_propose_redraw(lp, C.byref(cs), C.byref(run_), C.byref(io), 1, violations.data_ptr(), stream),
+                        "glabc_propose_redraw")
+        elif sentinel_redraw and algo == _capi.ALGO_GLMCMC:            # GLMCMC.py:92-93
             for rnd in range(1, max_redraws + 1):
                 if local_cb is None:
                     n_redrawn.zero_()
@@ -265,11 +273,18 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
             io.q_cur = keep["q"].data_ptr()
         _capi.check(lib.glabc_select(algo, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_select")
 
-    capturable = (local_cb is None and global_cb is None and not (sentinel_redraw and algo == _capi.ALGO_GLMCMC)
-                  and progress is None)
+    # Graph replay.  Without a sentinel check (GlobalMCMC, sentinel_redraw=False) an iteration never visits the host.  WITH it
+    # (the default for GLMCMC) the replay is speculative: almost no prior ever returns the sentinel, so the captured iteration
+    # only counts the local candidates that hit it; the count is read once per segment of 64 iterations, and if it is ever
+    # non-zero the segment's start state is restored and the rest of the run goes through the eager loop with the reference's
+    # redraw -- the Philox draws depend on (chain, iteration) only, so the result is the eager path's either way.
+    plain = local_cb is None and global_cb is None and progress is None
+    speculative = plain and sentinel_redraw and algo == _capi.ALGO_GLMCMC
+    capturable = plain
     if graph is True and not capturable:
-        raise ValueError("graph=True needs descriptor proposals and no sentinel check (sentinel_redraw=False or GlobalMCMC)")
+        raise ValueError("graph=True needs descriptor proposals and no progress callback")
     use_graph = capturable and graph in ("auto", True) and num_ite > 8
+    violations = torch.zeros(1, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         i = 1
         if use_graph:
@@ -279,10 +294,26 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
                 i += 1
             use_graph = model.where != "cpu"
         if use_graph:
+            saved = [t.clone() for t in (chains.theta, chains.y, chains.log_w, chains.flags, chains.n_moves, prior_cur, kern_cur)]
+            live = [chains.theta, chains.y, chains.log_w, chains.flags, chains.n_moves, prior_cur, kern_cur]
+            if stats is not None:
+                live += [stats.sum_theta, stats.sum_outer, stats.sum_jump]
+                saved += [t.clone() for t in (stats.sum_theta, stats.sum_outer, stats.sum_jump)]
+
+            def snapshot():
+                for a_, b_ in zip(saved, live):
+                    a_.copy_(b_)
+
+            def restore():
+                for a_, b_ in zip(saved, live):
+                    b_.copy_(a_)
+
             step_t = torch.tensor([i], dtype=torch.int32, device=dev)          # the iteration index, on the device
             run_.step0, run_.step0_device = 1, step_t.data_ptr()
             run_.history = hist_ptr + hist_row_bytes if hist is not None else None   # row 0 of `history` = iteration 1
             g = torch.cuda.CUDAGraph()
+            speculating[0] = speculative
+            snapshot()
             try:
                 side = torch.cuda.Stream(dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
@@ -290,7 +321,6 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
                     iteration(None)
                     step_t.add_(1)
                 torch.cuda.current_stream(dev).wait_stream(side)
-                i += 1
                 with torch.cuda.graph(g):
                     iteration(None)
                     step_t.add_(1)
@@ -299,11 +329,27 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
                     raise
                 torch.cuda.synchronize(dev)
                 g = None
-                i = int(step_t.item())
             run_.step0_device = None
-            if g is not None:
-                for _ in range(i, num_ite):
+            done = 1 if g is not None else 0                                    # the warm-up iteration belongs to the first segment
+            if g is None:                                                       # (a failed capture may have run part of an iteration)
+                restore()
+            while g is not None and i + done < num_ite:
+                k = min(64 - done, num_ite - i - done)
+                for _ in range(k):
                     g.replay()
+                done += k
+                if speculative and int(violations.item()) != 0:                 # one synchronisation per segment
+                    restore()
+                    g = None
+                    if state_out is not None:
+                        state_out["graph_rolled_back_at"] = i
+                    break
+                i += done
+                done = 0
+                if speculative and i < num_ite:
+                    snapshot()
+            speculating[0] = False
+            if g is not None:
                 i = num_ite
                 if state_out is not None:
                     state_out["graph"] = True
