@@ -575,3 +575,42 @@ def test_hip_theta_dim_beyond_the_descriptor_limit(hip):
     assert np.all(np.abs(late - want_sq) < 0.03 * want_sq), (late, want_sq)
     out2 = GlobalMCMC(m, 51, th0, y0, ip, None, 0.2, lp, seed=4, verbose=False)
     assert out2.shape == (51, n, d) and torch.isfinite(out2).all()
+
+
+@pytest.mark.gpu
+def test_hip_speculative_graph_replay_with_the_sentinel_check(hip, oracle):
+    """GLMCMC's default (sentinel check on) replays a captured iteration speculatively: (a) a prior that never returns the
+    sentinel -- the whole run is replayed and equals the eager loop bit for bit over several 64-iteration segments; (b) a prior
+    that does -- the first hit rolls the segment back and the eager loop with the reference's redraw takes over: still the
+    checker's chains."""
+    import glabcmcmc_amd as g_
+    from test_stream_independence import abs_gauss_model, proposals
+    g = load_golden("glmcmc_philox_bench")
+    cfg = g["cfg"]
+    model, local, glob = descriptors(cfg, g)
+    n = g["theta0"].shape[0]
+    th0, y0 = torch.from_numpy(g["theta0"]), torch.from_numpy(g["y0"])
+    T = 200
+    outs = {}
+    for mode in ("auto", False):
+        st = {}
+        outs[mode] = g_.GLMCMC(ProtocolModel(model), T + 1, th0, y0, FixedDescriptor(local), None, cfg["gf"], FixedDescriptor(glob),
+                               cfg["N"], seed=cfg["seed"], chain0=cfg.get("chain0", 0), verbose=False, graph=mode, state_out=st)
+        assert bool(st.get("graph")) == (mode == "auto") and "graph_rolled_back_at" not in st
+    assert np.array_equal(bits(outs["auto"].numpy()), bits(outs[False].numpy()))
+    Tg = min(T, cfg["T"])
+    assert np.array_equal(bits(outs["auto"].numpy()[:Tg + 1]), bits(g["chains"][:Tg + 1]))       # ... and the reference's
+    # (b)
+    rng = np.random.default_rng(3)
+    n, T, d = 256, 150, 2
+    bm = abs_gauss_model(d, 0.5)
+    lp, _ = proposals(d, "uniform")
+    ip = make_dist(("uniform", [0.9, 0.9], [2.0, 2.0])).descriptor()
+    theta0 = rng.uniform(1.0, 1.9, (n, d)).astype(np.float32)
+    y0b = (np.abs(theta0) + 0.2236 * rng.standard_normal((n, d))).astype(np.float32)
+    want, hc = oracle_split_phase(oracle, A.ALGO_GLMCMC, bm, lp, ip, theta0, y0b, T, 5, 0.3, 3, redraw_prior=box_prior(0.9, 2.0))
+    st = {}
+    out = g_.GLMCMC(BoxedModel(bm), T + 1, torch.from_numpy(theta0), torch.from_numpy(y0b), FixedDescriptor(lp), None, 0.3,
+                    FixedDescriptor(ip), 3, seed=5, verbose=False, state_out=st)
+    assert st.get("graph_rolled_back_at") == 4 and not st.get("graph")
+    assert np.array_equal(bits(out.numpy()[1:].transpose(0, 2, 1)), bits(want)) and hc.redraws > 100
