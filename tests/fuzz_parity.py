@@ -233,6 +233,8 @@ def one_case_rtc(rng, oracle, k):
     import glabcmcmc_amd as g_
     from test_rtc import host_simulator
     d, yd, nd = int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    if rng.random() < 0.4:
+        yd = d                                   # theta_dim == y_dim: the unit-Gaussian instantiation exists as well
     algo = "glmcmc" if rng.random() < 0.8 else "globalmcmc"
     N = int(rng.integers(1, 17)) if algo == "glmcmc" else 1
     src = random_simulator(rng, d, yd, nd)
@@ -241,7 +243,10 @@ def one_case_rtc(rng, oracle, k):
     eps = float(np.exp(rng.uniform(np.log(0.05), np.log(5))))
     gf = float(rng.choice([0.0, 1.0, rng.random()]))
     lspec, gspec = random_dist(rng, d, True), random_dist(rng, d, False)
-    prior = make_dist(("gauss", [0.0] * d, [float(v) for v in np.exp(rng.normal(0.2, 0.3, d))]))
+    unit = rng.random() < 0.5                     # unit prior + unit global proposal + y_obs away from 0 -> VAR_GAUSS_UNIT is launched
+    prior = make_dist(("gauss", [0.0] * d, [1.0] * d if unit else [float(v) for v in np.exp(rng.normal(0.2, 0.3, d))]))
+    if unit:
+        gspec = ("gauss", [0.0] * d, [1.0] * d)
     cm = g_.CompiledModel(d, yd, src, prior, [float(v) for v in rng.normal(0.8, 0.3, yd)], eps, noise_dim=nd)
     model = cm.descriptor()
     local, glob = make_dist(lspec).descriptor(), make_dist(gspec).descriptor()
