@@ -652,7 +652,7 @@ def main():
     def one_step():
         if args.workload == "glmala":
             engine.run_glmala_steps(model, ip, mala, chains, K, 1 + step_idx[0] * K, seed, gf, NBATCH, history=hist,
-                                    moments=mom, steps_per_launch=K)
+                                    moments=mom, steps_per_launch=K, lanes_per_chain=args.lanes)
         else:
             entry = "glabc_globalmcmc_steps" if args.workload == "globalmcmc" else "glabc_glmcmc_steps"
             engine.run_steps(entry, model, lp, ip, chains, K, 1 + step_idx[0] * K, seed, gf, args.batch,

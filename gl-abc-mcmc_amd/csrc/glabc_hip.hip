@@ -11,8 +11,10 @@
 //   esjd_kernel<D>               ESJD.py:2-25 per chain from a chain-major history
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -712,6 +714,15 @@ static MalaArgs<D> pack_mala(const glabc_model* m, const glabc_dist* imp, const 
         a.eps_sq = p->eps_sq;
         a.num_grad = p->num_grad;
     }
+    a.lanes = r ? r->lanes_per_chain : 0;
+    // team kernel (glabc_mala.h): the main wavefront runs at s_setprio 1 -- it carries the serial part of an iteration, the helper
+    // fills the issue slots it leaves (37.9 against 43.9 ms per 2000 iterations of 65 536 chains) -- and takes the same share of
+    // the gradient items as a helper lane (credit 0; measured optimum, flat between -2 and +2).  GLABC_MALA_PRIO /
+    // GLABC_MALA_CREDIT override both for tuning runs -- execution strategy only, never results
+    a.credit = 0;
+    if (const char* e = std::getenv("GLABC_MALA_CREDIT")) a.credit = std::max(-64, std::min(64, std::atoi(e)));
+    a.prio = 1;
+    if (const char* e = std::getenv("GLABC_MALA_PRIO")) a.prio = std::max(0, std::min(3, std::atoi(e)));
     return a;
 }
 
@@ -746,6 +757,7 @@ __attribute__((visibility("default"))) int glabc_glmala_steps(const glabc_model*
     if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
     if (r->moments && (!r->moments->sum_theta || !r->moments->sum_outer || !r->moments->sum_jump)) return GLABC_ERR_NULL;
     if (r->tape) return GLABC_ERR_ARG;
+    if (r->lanes_per_chain < 0 || r->lanes_per_chain > 2) return GLABC_ERR_ARG;      // wavefronts per 64 chains (theta_dim 2)
     if ((uint64_t)r->step0 + (uint64_t)r->n_steps > 0xFFFFFFFFull) return GLABC_ERR_ARG;
     if (c->n_chains == 0 || r->n_steps == 0) return GLABC_OK;
     hipStream_t s = (hipStream_t)stream;

@@ -32,6 +32,10 @@ struct MalaArgs {
     double* grad;
     double tau, tau_sq, eps_sq;
     int32_t num_grad;
+    int32_t lanes;               // glabc_run.lanes_per_chain: 0 = choose, 1 = one wavefront per 64 chains (glmala_kernel), 2 = a team
+                                 // of two wavefronts per 64 chains (glmala_team_kernel, theta_dim 2)
+    int32_t credit;              // team kernel: gradient work items the main wavefront's lanes are let off for running the iSIR move
+    int32_t prio;                // team kernel: s_setprio of the main wavefront (it carries the serial part of an iteration)
 };
 
 // ATen's float64 row sum: the float32 scheme of aten_rowsum with 4-wide vectors (probed)
@@ -622,8 +626,9 @@ GLABC_DEV bool mala_isir_move(const MalaArgs<D>& m, const Rng& rng, uint32_t ste
     return moved;
 }
 
+// At most 256 registers (amdgpu_waves_per_eu): launches of more than one wavefront per SIMD then run two per SIMD.
 template <int D, int N, bool LEAN>
-__global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) glmala_kernel(const MalaArgs<D> m)
 {
     const StepArgs<D>& a = m.s;
     __shared__ GradShared gsh;
@@ -689,6 +694,407 @@ __global__ void __launch_bounds__(64) glmala_kernel(const MalaArgs<D> m)
 #pragma unroll
         for (int j = 0; j < D; ++j) cur[j] = (float)c.theta[j];                              // Theta_Re is float32, :148,180,200
 
+        if (hist && valid) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) hist[((int64_t)t * D + j) * a.hist_stride] = cur[j];
+        }
+        if (mom) {
+            int k = 0;
+#pragma unroll
+            for (int p = 0; p < D; ++p) {
+                s1[p] += (double)cur[p];
+#pragma unroll
+                for (int q = p; q < D; ++q, ++k) {
+                    s2[k] += (double)cur[p] * (double)cur[q];
+                    double dp = (double)cur[p] - (double)prev[p];
+                    double dq = (double)cur[q] - (double)prev[q];
+                    sj[k] += dp * dq;
+                }
+            }
+        }
+    }
+
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        m.theta64[j * a.stride + i] = c.theta[j];
+        m.y64[j * a.stride + i] = c.y[j];
+        m.grad[j * a.stride + i] = c.grad[j];
+        a.theta[j * a.stride + i] = (float)c.theta[j];
+        a.y[j * a.stride + i] = (float)c.y[j];
+    }
+    m.log_w64[i] = c.log_w;
+    if (a.log_w) a.log_w[i] = (float)c.log_w;
+    a.flags[i] = c.flags;
+    if (a.n_moves) a.n_moves[i] = c.n_moves;
+    if (mom) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) a.sum_theta[j * a.stride + i] = s1[j];
+#pragma unroll
+        for (int k = 0; k < TRI; ++k) {
+            a.sum_outer[k * a.stride + i] = s2[k];
+            a.sum_jump[k * a.stride + i] = sj[k];
+        }
+    }
+}
+
+// ---- theta_dim 2: a TEAM of NW wavefronts per 64 chains ---------------------------------------------------------------------
+//
+// 65 536 chains are 1024 wavefronts of glmala_kernel: ONE per SIMD, which issues a vector instruction at best every other
+// slot and has nothing to cover its LDS atomics with (profiles/r02_pmc_glmala.json: 73 % VALU-active at 4.1 cycles per
+// instruction).  Halving the chains per wavefront does not help: ~40 % of an iteration's instructions are per wavefront, not
+// per chain (the iSIR move, the head draws, the end of a gradient) and would be paid twice (measured: 56.3 against 53.1 ms).
+// The team keeps them paid ONCE: wavefront 0 (the main wavefront) owns the 64 chains -- state in its registers, head draws,
+// iSIR move, MALA proposal, accept, Theta_Re row, sums -- and wavefronts 1..NW-1 only help with the one part that is dealt
+// flat over lanes anyway, the 2 * theta_dim * num_grad simulations of the finite-difference gradients.  While the helpers
+// work through the gradient items the main wavefront runs the iSIR move of the chains on the global branch (they are other
+// chains than the ones waiting for a gradient) and then takes a correspondingly smaller share of the items (`credit`).
+// 1024 workgroups x NW wavefronts = NW per SIMD.  Per iteration: the main wavefront publishes the chains that need a gradient
+// (theta, Philox counter) in LDS -> barrier -> every lane of the team walks its contiguous range of (chain, coordinate, Philox
+// block) items and adds its partial sums to the (chain, coordinate, side) accumulators in LDS (64-bit integer atomics: exact,
+// order-free) -> barrier -> the main wavefront finishes the statistics, four lanes per chain (coordinate x side), and the
+// owners take the accept decision.  A chain's first local move needs the gradient at its current state first (GLMALA.py:
+// 183-184): such an iteration runs the publish / items / finish sequence twice (round 0, then round 1).
+// Geometry only: every draw is a function of (seed, chain id, iteration, slot), the sums are exact integers, every float
+// operation is the one glmala_kernel performs -- tests/test_hip_parity.py holds both kernels to the checker bit for bit.
+struct TeamShared {
+    unsigned long long acc[64][2][2][4];   // [rank][coordinate][side +,-][s1, a, b, c] (glabc_fxsplit)
+    float th[64][2];                       // theta of the chain of that rank
+    uint32_t c0[64], c1[64];               // its Philox counter words (global chain id)
+    int n;                                 // chains published for this round
+    int round;                             // 0: gradients at the current states (GLMALA.py:183-184), 1: at the proposals (:187)
+};
+
+// this lane's share of the n * (blocks of coordinate 0 + blocks of coordinate 1) items of a round
+template <bool LEAN, int NW>
+GLABC_DEV void team_items(const MalaArgs<2>& m, uint32_t key0, uint32_t key1, uint32_t step, int g, int n, int wave, int lane,
+                          int credit, TeamShared* sh)
+{
+    constexpr int D = 2;
+    const StepArgs<D>& a = m.s;
+    const int num = m.num_grad;
+    const float h = 0.1f;
+    // a Philox block = the four normals of two consecutive simulations; coordinate k owns simulations k num .. k num + num - 1
+    const int nb0 = ((num - 1) >> 1) + 1;
+    const int blo1 = num >> 1, nb1 = ((2 * num - 1) >> 1) - blo1 + 1;
+    const int per = nb0 + nb1, total = n * per;
+    int q_m, q_h = 0;
+    if constexpr (NW == 1) {
+        q_m = (total + 63) >> 6;
+    } else {
+        constexpr int LH = 64 * (NW - 1);
+        int num_h = total + 64 * credit;                                // credit < 0: the main wavefront takes MORE than a helper
+        num_h = num_h > 0 ? num_h : 0;
+        q_h = (num_h + 64 * NW - 1) / (64 * NW);
+        q_m = q_h - credit;                                             // 64 q_m + LH q_h >= total
+        if (q_m < 0) {
+            q_m = 0;
+            q_h = (total + LH - 1) / LH;
+        }
+    }
+    int it0 = (wave == 0) ? lane * q_m : 64 * q_m + ((wave - 1) * 64 + lane) * q_h;
+    int it1 = it0 + ((wave == 0) ? q_m : q_h);
+    it1 = it1 < total ? it1 : total;
+    if (it0 >= it1) return;
+    int cur = it0 / per;
+    int r = it0 - cur * per;
+    int k = (r >= nb0) ? 1 : 0;
+    int bi = k ? r - nb0 : r;
+    float tp[D], tm[D];
+    double c_p = 0.0, c_m = 0.0;
+    uint32_t cc0 = 0u, cc1 = 0u;
+    glabc_fxsplit ap = {0, 0, 0, 0}, am = {0, 0, 0, 0};
+    auto enter = [&]() {                                                // the constants of (chain cur, coordinate k)
+        float zero[D], y0p[D], y0m[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float th = sh->th[cur][j];
+            tp[j] = th + (j == k ? h : 0.0f);                           // GLMALA.py:67
+            tm[j] = th - (j == k ? h : 0.0f);                           // GLMALA.py:68
+            zero[j] = 0.0f;
+        }
+        model_simulate<D>(a, tp, zero, y0p);                            // centres: the noise-free discrepancies
+        model_simulate<D>(a, tm, zero, y0m);
+        c_p = (double)model_discrepancy<D, LEAN>(a, y0p);
+        c_m = (double)model_discrepancy<D, LEAN>(a, y0m);
+        cc0 = sh->c0[cur];
+        cc1 = sh->c1[cur];
+    };
+    auto flush = [&]() {
+        unsigned long long* dst = &sh->acc[cur][k][0][0];
+        atomicAdd(dst + 0, (unsigned long long)ap.s1);
+        atomicAdd(dst + 1, ap.a);
+        atomicAdd(dst + 2, (unsigned long long)ap.b);
+        atomicAdd(dst + 3, ap.c);
+        atomicAdd(dst + 4, (unsigned long long)am.s1);
+        atomicAdd(dst + 5, am.a);
+        atomicAdd(dst + 6, (unsigned long long)am.b);
+        atomicAdd(dst + 7, am.c);
+        ap = glabc_fxsplit{0, 0, 0, 0};
+        am = glabc_fxsplit{0, 0, 0, 0};
+    };
+    auto one_sim = [&](const float (&eps)[D]) {
+        float yp[D], ym[D];
+        model_simulate<D>(a, tp, eps, yp);                              // GLMALA.py:78
+        model_simulate<D>(a, tm, eps, ym);                              // GLMALA.py:82 (same noise)
+        glabc_fxs_add(&ap, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, yp) - c_p));
+        glabc_fxs_add(&am, glabc_fx_quantize((double)model_discrepancy<D, LEAN>(a, ym) - c_m));
+    };
+    enter();
+#pragma unroll 1
+    for (int it = it0; it < it1; ++it) {
+        const int b = (k ? blo1 : 0) + bi;
+        glabc_u32x4 blk = glabc_philox4x32_10(cc0, cc1, step, GRAD_BASE + (uint32_t)g * GRAD_STRIDE + (uint32_t)b, key0, key1);
+        float e0[2], e1[2];
+        glabc_normal_pair(blk.v[0], blk.v[1], &e0[0], &e0[1]);
+        glabc_normal_pair(blk.v[2], blk.v[3], &e1[0], &e1[1]);
+        const int s0 = 2 * b - k * num, s1 = s0 + 1;                    // simulation indices within coordinate k
+        if (s0 >= 0 && s0 < num) one_sim(e0);
+        if (s1 >= 0 && s1 < num) one_sim(e1);
+        if (++bi == (k ? nb1 : nb0) && it + 1 < it1) {                  // the range crosses into the next (chain, coordinate)
+            flush();
+            bi = 0;
+            cur += k;
+            k ^= 1;
+            enter();
+        }
+    }
+    flush();
+}
+
+// End of a round, main wavefront (all 64 lanes call): the statistics of GLMALA.py:86-94 for the n published chains, one lane per
+// (chain, coordinate, side), then the owners (`need`, rank among the set bits of `mask`) assemble their gradient.  The
+// accumulators are left zero for the next round.
+template <bool LEAN>
+GLABC_DEV void team_finish(const MalaArgs<2>& m, bool need, unsigned long long mask, const float (&theta)[2], double (&grad)[2],
+                           TeamShared* sh)
+{
+    constexpr int D = 2;
+    const StepArgs<D>& a = m.s;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int n = __popcll(mask);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const float h = 0.1f, hp = 0.00001f;
+    const double nd = (double)m.num_grad;
+    double l4[4] = {0.0, 0.0, 0.0, 0.0};
+    const int passes = (4 * n + 63) >> 6;
+#pragma unroll 1
+    for (int p = 0; p < passes; ++p) {
+        const int job = p * 64 + lane;
+        const int r = job >> 2, k = (job >> 1) & 1, side = job & 1;
+        double l = 0.0;
+        if (r < n) {
+            unsigned long long* src = &sh->acc[r][k][side][0];
+            glabc_fxsplit sp;
+            sp.s1 = (int64_t)src[0]; sp.a = src[1]; sp.b = (int64_t)src[2]; sp.c = src[3];
+            src[0] = 0ull; src[1] = 0ull; src[2] = 0ull; src[3] = 0ull;
+            float o[D], zero[D], y0[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const float th = sh->th[r][j];
+                const float hh = (j == k) ? h : 0.0f;
+                o[j] = side ? th - hh : th + hh;                                             // GLMALA.py:67-68
+                zero[j] = 0.0f;
+            }
+            model_simulate<D>(a, o, zero, y0);
+            const double centre = (double)model_discrepancy<D, LEAN>(a, y0);
+            const glabc_fxsum f = glabc_fxs_finish(&sp);
+            const double s1 = glabc_fx_sum1(&f), s2 = glabc_fx_sum2(&f);
+            const double mu = centre + s1 / nd;                                              // GLMALA.py:86-87
+            const double var = (s2 - (s1 * s1) / nd) / (nd - 1.0);                           // :88-89
+            l = (-0.5 * glabc_log(var + m.eps_sq)) - ((0.5 * (mu * mu)) / (var + m.eps_sq)); // :90-93
+        }
+        const int src_lane = (rank & 15) << 2;
+        const double v0 = shfl_f64(l, src_lane), v1 = shfl_f64(l, src_lane + 1), v2 = shfl_f64(l, src_lane + 2),
+                     v3 = shfl_f64(l, src_lane + 3);
+        if (need && (rank >> 4) == p) {
+            l4[0] = v0; l4[1] = v1; l4[2] = v2; l4[3] = v3;
+        }
+    }
+    if (need) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double gll = (l4[2 * k] - l4[2 * k + 1]) / 0.2;                            // :94
+            float op[D], om[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                op[j] = theta[j] + (j == k ? hp : 0.0f);                                     // :84
+                om[j] = theta[j] - (j == k ? hp : 0.0f);
+            }
+            const float gp = (dist_log_prob<D>(a.prior, op) - dist_log_prob<D>(a.prior, om)) / 0.00002f;   // :84-85
+            grad[k] = gll + (double)gp;                                                      // :95
+        }
+    }
+}
+
+// main wavefront: hand the chains marked `need` (theta, Philox counter) to the team
+GLABC_DEV void team_publish(bool need, unsigned long long mask, const float (&theta)[2], const Rng& rng, int round, TeamShared* sh)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (need) {
+        sh->th[rank][0] = theta[0];
+        sh->th[rank][1] = theta[1];
+        sh->c0[rank] = rng.c0;
+        sh->c1[rank] = rng.c1;
+    }
+    if (lane == 0) {
+        sh->n = __popcll(mask);
+        sh->round = round;
+    }
+}
+
+template <int N, bool LEAN, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) glmala_team_kernel(const MalaArgs<2> m)
+{
+    constexpr int D = 2;
+    const StepArgs<D>& a = m.s;
+    __shared__ TeamShared sh;
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    {                                                                   // accumulators start at zero (team_finish keeps them so)
+        unsigned long long* z = &sh.acc[0][0][0][0];
+        for (int q = (int)threadIdx.x; q < 64 * 16; q += 64 * NW) z[q] = 0ull;
+    }
+    if (wave != 0) {                                                    // ---- helper wavefronts: gradient items only ----
+#pragma unroll 1
+        for (int t = 0; t < a.n_steps; ++t) {
+            const uint32_t step = a.step0 + (uint32_t)t;
+            __syncthreads();                                            // a round is published
+            if (sh.round == 0) {
+                team_items<LEAN, NW>(m, a.seed_lo, a.seed_hi, step, 0, sh.n, wave, lane, 0, &sh);
+                __syncthreads();                                        // round 0 summed
+                __syncthreads();                                        // round 1 published
+            }
+            team_items<LEAN, NW>(m, a.seed_lo, a.seed_hi, step, 1, sh.n, wave, lane, m.credit, &sh);
+            __syncthreads();                                            // round 1 summed
+        }
+        return;
+    }
+    // ---- main wavefront: the 64 chains ----
+    if (m.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (m.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (m.prio == 3) __builtin_amdgcn_s_setprio(3);
+    const int64_t tid = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = tid < a.n_chains;
+    const int64_t i = valid ? tid : a.n_chains - 1;          // tail lanes shadow the last chain (no stores)
+    MalaChain<D> c;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        c.theta[j] = m.theta64[j * a.stride + i];
+        c.y[j] = m.y64[j * a.stride + i];
+        c.grad[j] = m.grad[j * a.stride + i];
+    }
+    c.log_w = m.log_w64[i];
+    c.flags = a.flags[i];
+    c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
+
+    constexpr int TRI = D * (D + 1) / 2;
+    const bool mom = a.sum_theta != nullptr;
+    double s1[D], s2[TRI], sj[TRI];
+    if (mom) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) s1[j] = a.sum_theta[j * a.stride + i];
+#pragma unroll
+        for (int k = 0; k < TRI; ++k) {
+            s2[k] = a.sum_outer[k * a.stride + i];
+            sj[k] = a.sum_jump[k * a.stride + i];
+        }
+    }
+    const uint64_t gid = (uint64_t)(a.chain0 + i);
+    Rng rng;
+    rng.c0 = (uint32_t)gid;
+    rng.c1 = (uint32_t)(gid >> 32);
+    rng.k0 = a.seed_lo;
+    rng.k1 = a.seed_hi;
+    float* hist = a.history ? a.history + i : nullptr;
+    const float tauf = (float)m.tau;
+
+#pragma unroll 1
+    for (int t = 0; t < a.n_steps; ++t) {
+        const uint32_t step = a.step0 + (uint32_t)t;
+        float prev[D], cur[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) prev[j] = (float)c.theta[j];
+
+        glabc_u32x4 hd = glabc_philox4x32_10(rng.c0, rng.c1, step, 0u, rng.k0, rng.k1);
+        const bool is_global = glabc_uniform_f32(hd.v[0]) < a.gf;                            // GLMALA.py:151
+        const bool is_local = !is_global && valid;
+        float e[D], sn[D];
+        candidate_draws<D>(rng, step, 0, false, e, sn);                                      // the MALA move's z and simulator noise
+
+        // ---- round 0: grad_logABC_Theta_old of a chain's first local move, GLMALA.py:183-184 ----
+        const bool init = is_local && !(c.flags & GLABC_FLAG_HAS_GRAD);
+        const unsigned long long mask0 = __ballot(init);
+        float thf[D];
+        if (mask0 != 0ull) {                                                                 // wave-uniform
+#pragma unroll
+            for (int j = 0; j < D; ++j) thf[j] = (float)c.theta[j];                          // :62
+            team_publish(init, mask0, thf, rng, 0, &sh);
+            __syncthreads();
+            team_items<LEAN, NW>(m, rng.k0, rng.k1, step, 0, __popcll(mask0), 0, lane, 0, &sh);
+            __syncthreads();
+            team_finish<LEAN>(m, init, mask0, thf, c.grad, &sh);
+            if (init) c.flags |= GLABC_FLAG_HAS_GRAD;
+        }
+        // ---- Local_proposal_forward, GLMALA.py:25-44 ----
+        float tt[D];
+        double x[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) tt[j] = 0.0f + 0.5f * (e[j] * e[j]);
+        const float log_pro = (float)(-0.5 * (double)D * GLABC_LOG_2PI) - aten_rowsum<D>(tt);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float z = 0.0f + 1.0f * e[j];
+            const float av = z * tauf;
+            const double b = (c.flags & GLABC_FLAG_TH64) ? ((double)av + c.theta[j]) : (double)(av + (float)c.theta[j]);
+            x[j] = b + (c.grad[j] * m.tau_sq) / 2.0;                                         // :43
+            thf[j] = (float)x[j];                                                            // :62
+        }
+        // ---- round 1: the gradient at the proposal (:187) by the team, the iSIR move of the other chains meanwhile ----
+        const unsigned long long mask1 = __ballot(is_local);
+        team_publish(is_local, mask1, thf, rng, 1, &sh);
+        __syncthreads();
+        bool moved = false;
+        if (is_global) moved = mala_isir_move<D, N>(m, rng, step, glabc_uniform_f64(hd.v[2], hd.v[3]), c);
+        team_items<LEAN, NW>(m, rng.k0, rng.k1, step, 1, __popcll(mask1), 0, lane, m.credit, &sh);
+        __syncthreads();
+        double gprop[D] = {0.0, 0.0};
+        if (mask1 != 0ull) team_finish<LEAN>(m, is_local, mask1, thf, gprop, &sh);
+        if (is_local) {                                                                      // GLMALA.py:188-199
+            double y[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const float noise = a.noise_loc[j] + a.noise_scale[j] * sn[j];
+                y[j] = __builtin_fabs(x[j]) + (double)noise;                                 // :188-189
+            }
+            double tq[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double arg = ((c.theta[j] - x[j]) - (gprop[j] * m.tau_sq) / 2.0) / m.tau;   // :115
+                const double ee = (arg - 0.0) / 1.0;
+                tq[j] = 0.0 + 0.5 * (ee * ee);
+            }
+            const double lq_rev = (-0.5 * (double)D * GLABC_LOG_2PI) - aten_rowsum_f64<D>(tq);
+            double log_acc = dist_log_prob_f64<D>(a.prior, x) + model_log_kernel_f64<D>(a, y);    // :190
+            log_acc = log_acc + lq_rev;                                                      // :191
+            log_acc = log_acc - state_prior<D>(a, c);                                        // :192
+            log_acc = log_acc - state_kernel<D>(a, c);
+            log_acc = log_acc - (double)log_pro;                                             // :193
+            const double log_u = (double)glabc_logf(glabc_uniform_f32(hd.v[1]));             // :194
+            if (log_u < log_acc) {                                                           // :195-199
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    c.theta[j] = x[j];
+                    c.y[j] = y[j];
+                    c.grad[j] = gprop[j];
+                }
+                c.flags |= GLABC_FLAG_TH64;
+                moved = true;                    // `local` is NOT set: GLMALA.py:195-199 vs GLMCMC.py:100
+            }
+        }
+        c.n_moves += moved ? 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < D; ++j) cur[j] = (float)c.theta[j];                              // Theta_Re is float32, :148,180,200
         if (hist && valid) {
 #pragma unroll
             for (int j = 0; j < D; ++j) hist[((int64_t)t * D + j) * a.hist_stride] = cur[j];

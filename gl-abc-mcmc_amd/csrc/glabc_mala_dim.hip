@@ -12,6 +12,16 @@ template <int D, int N>
 static int launch_mala(const MalaArgs<D>& m, hipStream_t s)
 {
     const unsigned grid = (unsigned)((m.s.n_chains + 63) / 64);
+    if constexpr (D == 2) {
+        // theta_dim 2: launches of fewer than two wavefronts of glmala_kernel per SIMD (1024 SIMDs) run as teams of two wavefronts
+        // per 64 chains (glabc_mala.h glmala_team_kernel; lanes_per_chain 1 / 2 force one / two wavefronts)
+        const int nw = m.lanes ? m.lanes : (grid < 2048u ? 2 : 1);
+        if (nw == 2) {
+            if (m.s.y_obs_away) hipLaunchKernelGGL((glmala_team_kernel<N, true, 2>), dim3(grid), dim3(128), 0, s, m);
+            else hipLaunchKernelGGL((glmala_team_kernel<N, false, 2>), dim3(grid), dim3(128), 0, s, m);
+            return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
+        }
+    }
     if (m.s.y_obs_away)
         hipLaunchKernelGGL((glmala_kernel<D, N, true>), dim3(grid), dim3(64), 0, s, m);
     else

@@ -191,8 +191,10 @@ def glmala_init(model_desc, chains):
 
 
 def run_glmala_steps(model_desc, importance_desc, mala, chains, n_steps, step0, seed, global_frequency, batch_size,
-                     history=None, moments=None, steps_per_launch=None):
-    """GLMALA twin of run_steps (entry point glabc_glmala_steps); `mala` is a _capi.Mala."""
+                     history=None, moments=None, steps_per_launch=None, lanes_per_chain=0):
+    """GLMALA twin of run_steps (entry point glabc_glmala_steps); `mala` is a _capi.Mala.
+    lanes_per_chain: 0 = let the library choose; 1 = 64 chains per wavefront, 2 = 32 (the other 32 lanes only help with the
+    wave-cooperative gradient) -- launch geometry, results are identical."""
     lib = _capi.lib()
     k_max = int(steps_per_launch or MAX_STEPS_PER_LAUNCH)
     cs = chains.struct()
@@ -208,6 +210,7 @@ def run_glmala_steps(model_desc, importance_desc, mala, chains, n_steps, step0, 
             run.n_steps = k
             run.global_frequency = float(global_frequency)
             run.batch_size = int(batch_size)
+            run.lanes_per_chain = int(lanes_per_chain)
             if history is not None:
                 run.history = history[done].data_ptr()
                 run.hist_stride = chains.n

@@ -1,6 +1,6 @@
 """Randomised differential test, gfx950 kernels vs the CPU checker (not collected by pytest; run on the GPU box):
 
-    python tests/fuzz_parity.py [seconds] [seed] [rtc | nfgrad]
+    python tests/fuzz_parity.py [seconds] [seed] [rtc | nfgrad | mala]
 
 Random theta_dim, batch size (every fourth GLMCMC case beyond 16: the wide kernel, up to 1200 proposals), epsilon (1e-4 .. 10), global_frequency, Gaussian / Uniform proposals with random
 parameters, y_obs (also near zero), lanes per chain, iterations per launch, chain id offsets -- GLMCMC and GlobalMCMC
@@ -117,6 +117,7 @@ def one_case_mala(rng, oracle, k):
     mala = _capi.Mala(tau, tau ** 2, eps ** 2, num, 0)
     n, T = int(rng.integers(1, 200)), int(rng.integers(1, 40))
     spl = int(rng.integers(1, T + 1))
+    lanes = int(rng.integers(0, 3))             # launch geometry: the library's choice / one / two wavefronts per 64 chains
     seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
     theta0 = rng.normal(0, 1, (n, d)).astype(np.float32)
     y0 = (np.abs(theta0) + 0.2236068 * rng.normal(0, 1, (n, d))).astype(np.float32)
@@ -124,7 +125,8 @@ def one_case_mala(rng, oracle, k):
     chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0).add_mala_state()
     engine.glmala_init(model, chains)
     hist = torch.empty(T, d, n, device=dev)
-    engine.run_glmala_steps(model, glob, mala, chains, T, 1, seed, gf, N, history=hist, steps_per_launch=spl)
+    engine.run_glmala_steps(model, glob, mala, chains, T, 1, seed, gf, N, history=hist, steps_per_launch=spl,
+                            lanes_per_chain=lanes)
     torch.cuda.synchronize()
     hc = oracle_lib.HostChains(theta0, y0, chain0=chain0).add_mala_state()
     hh = np.zeros((T, d, n), np.float32)
@@ -132,7 +134,8 @@ def one_case_mala(rng, oracle, k):
     cs = hc.struct()
     assert oracle.oracle_glmala_init(C.byref(model), C.byref(cs)) == 0
     assert oracle.oracle_glmala_steps(C.byref(model), C.byref(glob), C.byref(mala), C.byref(cs), C.byref(run)) == 0
-    desc = dict(case=k, algo="glmala", d=d, N=N, eps=eps, gf=gf, tau=tau, num=num, glob=gspec, y_obs=y_obs, n=n, T=T, spl=spl)
+    desc = dict(case=k, algo="glmala", d=d, N=N, eps=eps, gf=gf, tau=tau, num=num, glob=gspec, y_obs=y_obs, n=n, T=T, spl=spl,
+                lanes=lanes)
     ok = np.array_equal(bits(hist.cpu().numpy()), bits(hh)) and np.array_equal(chains.theta64.cpu().numpy(), hc.theta64) \
         and np.array_equal(chains.y64.cpu().numpy(), hc.y64) and np.array_equal(chains.log_w64.cpu().numpy(), hc.log_w64) \
         and np.array_equal(chains.grad.cpu().numpy(), hc.grad) \
@@ -328,9 +331,10 @@ def main():
     _capi.lib()
     RTC_ONLY = len(sys.argv) > 3 and sys.argv[3] == "rtc"
     NF_ONLY = len(sys.argv) > 3 and sys.argv[3] == "nfgrad"
+    MALA_ONLY = len(sys.argv) > 3 and sys.argv[3] == "mala"
     t0, k, moves, bad = time.time(), 0, 0, []
     while time.time() - t0 < budget:
-        fn = one_case_nf_grad if (NF_ONLY or k % 64 == 17) else one_case_rtc if (RTC_ONLY or k % 16 == 6) else one_case_mala if k % 4 == 3 else one_case_gk if k % 8 == 5 else \
+        fn = one_case_mala if MALA_ONLY else one_case_nf_grad if (NF_ONLY or k % 64 == 17) else one_case_rtc if (RTC_ONLY or k % 16 == 6) else one_case_mala if k % 4 == 3 else one_case_gk if k % 8 == 5 else \
             one_case_nf if k % 32 == 9 else one_case
         ok, desc, mv = fn(rng, oracle, k)
         moves += mv

@@ -323,7 +323,7 @@ def test_bad_arguments_are_refused(hip):
 
 
 # ---------------------------------------------------------------------------------- GLMALA
-def hip_glmala(model, glob, mala, theta0, y0, T, seed, gf, N, chain0=0, steps_per_launch=None, moments=False):
+def hip_glmala(model, glob, mala, theta0, y0, T, seed, gf, N, chain0=0, steps_per_launch=None, moments=False, lanes=0):
     from glabcmcmc_amd import engine
     dev = torch.device("cuda", 0)
     chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0).add_mala_state()
@@ -331,7 +331,7 @@ def hip_glmala(model, glob, mala, theta0, y0, T, seed, gf, N, chain0=0, steps_pe
     hist = torch.empty(T, chains.d, chains.n, dtype=torch.float32, device=dev)
     mom = engine.Moments(chains.n, chains.d, dev) if moments else None
     engine.run_glmala_steps(model, glob, mala, chains, T, 1, seed, gf, N, history=hist, moments=mom,
-                            steps_per_launch=steps_per_launch)
+                            steps_per_launch=steps_per_launch, lanes_per_chain=lanes)
     torch.cuda.synchronize()
     return hist.cpu().numpy(), chains, mom
 
@@ -396,8 +396,9 @@ MALA_CASES = [
 ]
 
 
+@pytest.mark.parametrize("lanes", [1, 2])      # 64 / 32 chains per wavefront (glabc_mala.h glmala_kernel CPW)
 @pytest.mark.parametrize("case", MALA_CASES, ids=lambda c: "N%d-gf%g-num%d-%s" % (c[0], c[1], c[4], c[5][0]))
-def test_hip_glmala_equals_oracle(hip, oracle, case):
+def test_hip_glmala_equals_oracle(hip, oracle, case, lanes):
     N, gf, eps, tau, num, gspec, n, T = case
     cfg = dict(epsilon=eps, tau=tau, num_grad=num, local=("gauss", [0, 0], [1, 1]), **{"global": gspec})
     model, _, glob = descriptors(cfg)
@@ -409,7 +410,7 @@ def test_hip_glmala_equals_oracle(hip, oracle, case):
     y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, 2))).astype(np.float32)
     seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
     hist, chains, mom = hip_glmala(model, glob, mala, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True,
-                                   steps_per_launch=37)
+                                   steps_per_launch=37, lanes=lanes)
     hh, hc, hm = oracle_glmala(oracle, model, glob, mala, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True)
     same = bits(hist) == bits(hh)
     assert same.all(), "first mismatch at (t, dim, chain) = %s" % (np.argwhere(~same)[0],)
