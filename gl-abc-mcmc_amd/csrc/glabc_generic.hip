@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) propose_kernel(const GenArgs a)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int gi = 4 * b + t;
-                if (gi - DP < ND) noise_row[gi - DP] = nrm[t];
+                if (gi >= DP && gi - DP < ND) noise_row[gi - DP] = nrm[t];      // theta_dim > 8: words 8 .. DP-1 are proposal words
             }
         }
     }

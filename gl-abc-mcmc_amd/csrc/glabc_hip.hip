@@ -21,6 +21,7 @@
 #include "glabc_mala.h"
 #include "glabc_pack.h"
 #include "glabc_sampler.h"
+#include "glabc_team.h"
 
 namespace glabc {
 
@@ -665,6 +666,34 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
         default: return GLABC_ERR_DIM;
         }
     }
+    // Team geometry (glabc_team.h): two wavefronts per 64 chains, for launches that would otherwise leave the SIMDs with at most
+    // two wavefronts of sampler_kernel each.  Chosen when the caller leaves the geometry to the library.
+    if (algo == ALGO_GLMCMC && !r->tape && !(r->debug_flags & GLABC_DEBUG_NO_TEAM) &&
+        ((r->debug_flags & GLABC_DEBUG_TEAM) || (r->lanes_per_chain == 0 && c->n_chains >= 64 * 256 && c->n_chains <= 2 * 1024 * 64))) {
+        int prio = 1;                                       // the main wavefront carries the serial part of an iteration
+        if (const char* e = std::getenv("GLABC_TEAM_PRIO")) prio = std::max(0, std::min(3, std::atoi(e)));
+        // wavefronts per 64 chains: enough for about three wavefronts per SIMD (1024 SIMDs)
+        const int64_t groups = (c->n_chains + 63) / 64;
+        int nw = groups <= 1024 ? 3 : 2;
+        if (const char* e = std::getenv("GLABC_TEAM_WAVES")) nw = std::max(2, std::min(4, std::atoi(e)));
+        rc = GLABC_ERR_ARG;
+        for (; nw >= 2 && rc == GLABC_ERR_ARG; --nw) {      // fewer wavefronts when the batch is too small to split that far
+            if (m->sim_kind == GLABC_SIM_GK) {
+                rc = launch_team_dim<4, 8>(r->batch_size, nw, pack_args<4, 8>(m, local, global, c, r), prio, s);
+            } else {
+                switch (m->theta_dim) {
+#define GLABC_TEAM_CASE(d) case d: rc = launch_team_dim<d, d>(r->batch_size, nw, pack_args<d>(m, local, global, c, r), prio, s); break;
+                    GLABC_TEAM_CASE(1) GLABC_TEAM_CASE(2) GLABC_TEAM_CASE(3) GLABC_TEAM_CASE(4)
+#undef GLABC_TEAM_CASE
+                default: nw = 0; break;
+                }
+            }
+        }
+        if (rc != GLABC_ERR_ARG) {                          // GLABC_ERR_ARG: no team kernel for this configuration
+            if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
+            return rc;
+        }
+    }
     const int lanes = (algo == ALGO_GLMCMC && !r->tape) ? pick_lanes(r->lanes_per_chain, r->batch_size, c->n_chains) : 1;
     // Two builds of the same kernels: up to two waves per SIMD (131 072 lanes on this part) a launch is latency-bound
     // and runs the max-ilp schedule (217 VGPRs, 6 % faster at 65 536 chains); larger launches need the occupancy
@@ -1167,6 +1196,7 @@ __attribute__((visibility("default"))) int glabc_selftest_sqrt(uint32_t first_bi
 }
 
 __attribute__((visibility("default"))) int glabc_version(void) { return GLABC_VERSION; }
+__attribute__((visibility("default"))) int glabc_stream_layout(void) { return GLABC_STREAM_LAYOUT; }
 
 __attribute__((visibility("default"))) const char* glabc_status_string(int status)
 {

@@ -31,6 +31,7 @@
 
 #include "../../include/glabc.h"
 #include "../../include/glabc_numerics.h"
+#include "glabc_lds_grant.h"
 #include "glabc_nf_layout.h"
 
 namespace glabc {
@@ -387,12 +388,8 @@ static int nf_launch_mode(NfArgs a, int rows_per_wg, int slots_per_wave, hipStre
     a.rows_per_wg = rows_per_wg;
     a.state_floats_per_wave = 192 * slots_per_wave;
     const size_t lds_bytes = sizeof(float) * ((size_t)NF_BLOCK_FLOATS + (size_t)NF_WAVES * a.state_floats_per_wave);
-    static size_t attr_bytes = 0;                        // the largest dynamic LDS size this instantiation was allowed so far
-    if (lds_bytes > attr_bytes) {
-        if (hipFuncSetAttribute((const void*)nf_kernel<INV, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return GLABC_ERR_LAUNCH;
-        attr_bytes = lds_bytes;
-    }
+    static LdsGrant grant;                               // the largest dynamic LDS size this instantiation was allowed so far, per device
+    if (!grant_dynamic_lds(grant, (const void*)nf_kernel<INV, TILE>, lds_bytes, 0)) return GLABC_ERR_LAUNCH;
     const unsigned grid = (unsigned)((a.n_rows + rows_per_wg - 1) / rows_per_wg);
     hipLaunchKernelGGL((nf_kernel<INV, TILE>), dim3(grid), dim3(64 * NF_WAVES), lds_bytes, s, a);
     return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;

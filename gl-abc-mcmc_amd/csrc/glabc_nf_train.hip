@@ -44,6 +44,7 @@
 
 #include "../../include/glabc.h"
 #include "../../include/glabc_numerics.h"
+#include "glabc_lds_grant.h"
 #include "glabc_nf_layout.h"
 
 namespace glabc {
@@ -782,11 +783,13 @@ __attribute__((visibility("default"))) int glabc_nf_grad(const glabc_flow* flow,
     static int variant = 0;
     if (!variant) {
         const char* e = std::getenv("GLABC_NF_BW");
-        const int want = (e && e[0] == '1') ? 1 : (e && e[0] == '4') ? 4 : 8;
-        const void* fn = want == 1 ? (const void*)nf_backward_kernel : want == 4 ? (const void*)nf_backward_kernel2<4> : (const void*)nf_backward_kernel2<8>;
-        const int bytes = (want == 1 ? B_FLOATS : want == 4 ? BwLds<4>::FLOATS : BwLds<8>::FLOATS) * 4;
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return GLABC_ERR_LAUNCH;
-        variant = want;
+        variant = (e && e[0] == '1') ? 1 : (e && e[0] == '4') ? 4 : 8;
+    }
+    {
+        static LdsGrant grant;                           // per device: a second GPU driven by the same process needs its own grant
+        const void* fn = variant == 1 ? (const void*)nf_backward_kernel : variant == 4 ? (const void*)nf_backward_kernel2<4> : (const void*)nf_backward_kernel2<8>;
+        const int bytes = (variant == 1 ? B_FLOATS : variant == 4 ? BwLds<4>::FLOATS : BwLds<8>::FLOATS) * 4;
+        if (!grant_dynamic_lds(grant, fn, (size_t)bytes, 0)) return GLABC_ERR_LAUNCH;
     }
     int rows_per_wg;
     const int wgs = wgs_for(n_rows, &rows_per_wg, variant == 4 ? 2 * BW_MAX_WGS : BW_MAX_WGS, variant == 8 ? 256 : BW_ROWS);

@@ -24,6 +24,7 @@
 
 #include <cstdint>
 
+#include "glabc_lds_grant.h"
 #include "glabc_sampler.h"
 
 namespace glabc {
@@ -331,12 +332,8 @@ static int launch_wide_l(const StepArgs<D, YD>& a, int N, hipStream_t s)
 {
     constexpr int GROUPS = WIDE_BLOCK / L;
     const size_t lds = sizeof(float) * (size_t)GROUPS * (size_t)(N + 1 + 32);
-    static size_t allowed = 48 * 1024;
-    if (lds > allowed) {
-        if (hipFuncSetAttribute((const void*)wide_kernel<D, YD, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return GLABC_ERR_LAUNCH;
-        allowed = lds;
-    }
+    static LdsGrant grant;                               // per instantiation, per device
+    if (!grant_dynamic_lds(grant, (const void*)wide_kernel<D, YD, L>, lds)) return GLABC_ERR_LAUNCH;
     const unsigned grid = (unsigned)((a.n_chains + GROUPS - 1) / GROUPS);
     hipLaunchKernelGGL((wide_kernel<D, YD, L>), dim3(grid), dim3(WIDE_BLOCK), lds, s, a, N);
     return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;

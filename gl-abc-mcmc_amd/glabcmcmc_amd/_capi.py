@@ -21,8 +21,13 @@ SIM_ABS_GAUSS = 0
 SIM_GK = 1
 SIM_USER = 2
 
+VERSION = 300                  # include/glabc.h GLABC_VERSION
+STREAM_LAYOUT = 2              # include/glabc.h GLABC_STREAM_LAYOUT
+
 FLAG_LOCAL = 1
 DEBUG_EXACT_INDEX = 1          # glabc_run.debug_flags
+DEBUG_NO_TEAM = 2              # glabc_glmcmc_steps: never / always the two-wavefront team geometry (csrc/glabc_team.h)
+DEBUG_TEAM = 4
 FLAG_TH64 = 2
 FLAG_LW64 = 4
 FLAG_HAS_GRAD = 8
@@ -269,6 +274,7 @@ ENTRY_POINTS = {
     "glabc_selftest_sqrt": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "glabc_selftest_rowsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "glabc_version": (C.c_int, []),
+    "glabc_stream_layout": (C.c_int, []),
     "glabc_status_string": (C.c_char_p, [C.c_int]),
     "glabc_last_hip_error": (C.c_int, []),
 }
@@ -298,6 +304,10 @@ def lib():
             fn = getattr(handle, name)     # AttributeError here = ABI mismatch, deliberately loud
             fn.restype = res
             fn.argtypes = args
+        got = handle.glabc_version()
+        if got != VERSION:                 # a stale library would misread the argument structs (include/glabc.h GLABC_VERSION)
+            raise HipLibraryMissing("%s is version %d, this binding is for %d: rebuild it (python __graft_entry__.py build)"
+                                    % (LIB_PATH, got, VERSION))
         _lib = handle
     return _lib
 

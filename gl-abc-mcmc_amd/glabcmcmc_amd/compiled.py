@@ -52,10 +52,13 @@ class CompiledModel:
         self.epsilon = epsilon
         self._programs = {}
         self._checked = set()
+        self._failed = {}                                 # (algorithm, batch size) -> message of the failed self-check
 
     # ---- run-time compiled programs, one per (algorithm, batch size) -------------------------------------------------
     def program(self, algo, batch_size=1):
         key = (int(algo), 1 if algo == _capi.ALGO_GLOBALMCMC else int(batch_size))
+        if key in self._failed:
+            raise SimulatorSelfCheckError(self._failed[key])
         if key not in self._programs:
             handle = C.c_void_p()
             log = C.create_string_buffer(1 << 16)
@@ -65,8 +68,19 @@ class CompiledModel:
                 raise SimulatorCompileError("glabc_rtc_compile failed (status %d):\n%s" % (rc, log.value.decode(errors="replace")))
             self._programs[key] = handle
         if key not in self._checked and os.environ.get("GLABC_RTC_SELF_CHECK", "1") != "0":
-            self._checked.add(key)
-            self.self_check(*key)
+            self._checked.add(key)                       # before the check: self_check re-enters program() through the samplers
+            try:
+                self.self_check(*key)
+            except BaseException as exc:
+                # a program that failed (or did not finish) its check must never be handed out: release it, and keep the
+                # verdict so that every later call raises again instead of sampling with a miscompiled kernel
+                self._checked.discard(key)
+                handle = self._programs.pop(key, None)
+                if handle is not None:
+                    _capi.lib().glabc_rtc_release(handle)
+                if isinstance(exc, SimulatorSelfCheckError):
+                    self._failed[key] = str(exc)
+                raise
         return self._programs[key]
 
     def self_check(self, algo, batch_size=1, n_chains=512, steps=4, seed=20240229):

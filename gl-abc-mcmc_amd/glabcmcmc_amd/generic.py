@@ -365,6 +365,18 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
 
 
 # ------------------------------------------------------------------------------------------- pool samplers (GLMCMC_NF, AGLMCMC)
+def _noise_seed(key, chain0):
+    """Seed of the torch generator that draws a callback Model's simulator noise (pool rows, MALA gradient estimates).  Every
+    rank of a sharded run is given the same `seed` and its own chain0 (parallel.shard_range); the generator's stream must
+    differ between shards, or chains on different GPUs would share their simulator noise -- so chain0 is hashed in
+    (splitmix64 finaliser).  One shard (chain0 = 0) keeps the seed's own stream."""
+    z = (int(chain0) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    z ^= z >> 31
+    return (int(key) ^ z) & 0x7FFFFFFFFFFFFFFF
+
+
 class PoolSampler:
     """One chain-state + iteration engine shared by the callback forms of GLMCMC_NF and AGLMCMC: every chain owns a pool of
     P = batch_size*step_size proposals (row r = p*n + c), a global move is the iSIR step against the chain's next slice
@@ -387,7 +399,7 @@ class PoolSampler:
         self.local_desc = dist_descriptor(Local_Proposal, d)
         self.local_cb = ProposalCallbacks(Local_Proposal, dev) if self.local_desc is None else None
         self.gen = torch.Generator(device=dev)
-        self.gen.manual_seed(self.key & 0x7FFFFFFFFFFFFFFF)
+        self.gen.manual_seed(_noise_seed(self.key, chain0))
         f32 = dict(dtype=torch.float32, device=dev)
         self.theta_prop = torch.zeros(R, d, **f32)
         self.log_q = torch.zeros(R, **f32)
@@ -706,8 +718,8 @@ def run_glmala(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad, fileloc
     tau = float(tau)
     eps_sq = float(ABCset.epsilon) ** 2                                                          # GLMALA.py:90
     gen = torch.Generator(device=dev)
-    gen.manual_seed(key & 0x7FFFFFFFFFFFFFFF)
-    host_rng = np.random.Generator(np.random.PCG64(key))
+    gen.manual_seed(_noise_seed(key, chain0))
+    host_rng = np.random.Generator(np.random.PCG64(_noise_seed(key, chain0)))
 
     def discrepancy(y):
         return model._call(lambda cuda: model._back(ABCset.discrepancy(y if cuda else y.cpu()), y.shape[0])).view(-1)

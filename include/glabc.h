@@ -41,7 +41,12 @@
 extern "C" {
 #endif
 
-#define GLABC_VERSION 100          /* 0.1.0 */
+#define GLABC_VERSION 300          /* 0.3.0: bumped whenever a struct of this header changes (the Python binding refuses a library
+                                      of another version: a stale .so would misread the argument blocks) */
+/* Layout of the random stream (include/glabc_numerics.h): which Philox (counter, slot, word) a draw of (chain, iteration) reads.
+ * A checkpoint stores it; resuming on another layout would continue on a different stream.  2 = simulator normals start at an
+ * even word (round 2), NF pool rows keyed (refresh << 44) + chain0 * P + r. */
+#define GLABC_STREAM_LAYOUT 2
 #define GLABC_MAX_DIM 8            /* theta_dim, y_dim, distribution dim */
 #define GLABC_MAX_BATCH 16         /* iSIR proposals per step held in registers (one to four lanes per chain) */
 #define GLABC_MAX_BATCH_WIDE 4096  /* glabc_glmcmc_steps beyond that: 8 to 64 lanes of a wavefront share a chain's proposals */
@@ -181,6 +186,11 @@ typedef struct glabc_run {
  * lies within 4e-6 of a partial sum (the two cannot disagree otherwise: the fast partial sums are within 1.3e-6 of
  * the reference's).  This bit takes the reference's path always -- tests use it to show both give the same chains. */
 #define GLABC_DEBUG_EXACT_INDEX 1
+/* glabc_glmcmc_steps, batch_size 2..GLABC_MAX_BATCH: launches of at most two wavefronts per SIMD run as TEAMS of two wavefronts per
+ * 64 chains (csrc/glabc_team.h: one holds the chains and takes the decisions, the other evaluates half of the candidates one
+ * iteration ahead).  These bits forbid / force that geometry -- tests use them to show that both give the same chains. */
+#define GLABC_DEBUG_NO_TEAM 2
+#define GLABC_DEBUG_TEAM 4
 
 /* ---- entry points ------------------------------------------------------------ */
 
@@ -525,6 +535,7 @@ int glabc_selftest_sqrt(uint32_t first_bits, uint32_t last_bits, uint64_t* misma
 int glabc_selftest_rowsum(const float* x, int32_t n_rows, int32_t n, float* out, void* stream);
 
 int glabc_version(void);
+int glabc_stream_layout(void);
 const char* glabc_status_string(int status);
 int glabc_last_hip_error(void);    /* hipError_t of the most recent failed launch on this thread */
 

@@ -1784,7 +1784,7 @@ static void candidate_draws(uint64_t seed, uint64_t chain, uint32_t step, int j,
         glabc_normal_pair(o.v[2], o.v[3], &nrm[2], &nrm[3]);
         for (int t = 0; t < 4; ++t) {
             int g = 4 * b + t;
-            if (g < d) e[g] = uniform ? glabc_uniform_f32(o.v[t]) : nrm[t];
+            if (g < d && g < GLABC_MAX_DIM) e[g] = uniform ? glabc_uniform_f32(o.v[t]) : nrm[t];   /* d > 8: callback proposals, e unused */
             if (noise && g >= dp && g - dp < nd) noise[g - dp] = nrm[t];
         }
     }

@@ -614,3 +614,41 @@ def test_hip_speculative_graph_replay_with_the_sentinel_check(hip, oracle):
                     FixedDescriptor(ip), 3, seed=5, verbose=False, state_out=st)
     assert st.get("graph_rolled_back_at") == 4 and not st.get("graph")
     assert np.array_equal(bits(out.numpy()[1:].transpose(0, 2, 1)), bits(want)) and hc.redraws > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,nd", [(12, 3), (9, 5), (11, 1), (8, 7), (3, 6)])
+def test_hip_propose_noise_rows_beyond_eight_proposal_words(hip, oracle, d, nd):
+    """glabc_propose with callback proposals (no descriptor: theta_dim may exceed GLABC_MAX_DIM) and a Model that takes its
+    simulator noise from the stream (noise_dim > 0): Philox words 8 .. DP-1 of a candidate are proposal words, not simulator
+    normals -- an earlier propose_kernel wrote them in front of the candidate's noise row.  Every row equals the CPU
+    checker's, and the guard bands around the buffer stay untouched."""
+    from glabcmcmc_amd import engine
+    dev = torch.device("cuda", 0)
+    n, N, seed = 77, 4, 991
+    chains = engine.ChainBatch(torch.zeros(n, d), torch.zeros(n, 2), dev, chain0=5)
+    cs = chains.struct()
+    R, G = N * n, 64
+    noise = torch.full((R * nd + 2 * G,), 7.25, dtype=torch.float32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    buf = dict(theta_prop=torch.zeros(R, d, **f32), log_q=torch.zeros(R, **f32), log_u=torch.zeros(n, **f32),
+               u_res=torch.zeros(n, dtype=torch.float64, device=dev), is_global=torch.zeros(n, dtype=torch.int32, device=dev))
+    io = A.StepIO(N, d, 2, nd, buf["theta_prop"].data_ptr(), buf["log_q"].data_ptr(), noise.data_ptr() + 4 * G,
+                  buf["log_u"].data_ptr(), buf["u_res"].data_ptr(), buf["is_global"].data_ptr(), None, None, None, None, None, None)
+    run = A.Run()
+    run.seed, run.step0, run.n_steps, run.global_frequency, run.batch_size = seed, 3, 1, 0.6, N
+    assert hip.glabc_propose(A.ALGO_GLMCMC, None, None, C.byref(cs), C.byref(run), C.byref(io), None) == 0
+    torch.cuda.synchronize()
+    got = noise.cpu().numpy()
+    assert (got[:G] == 7.25).all() and (got[-G:] == 7.25).all(), "glabc_propose wrote outside sim_noise"
+    hc = oracle_lib.HostChains(np.zeros((n, d), np.float32), np.zeros((n, 2), np.float32), chain0=5)
+    hcs = hc.struct()
+    h = dict(theta_prop=np.zeros((R, d), np.float32), log_q=np.zeros(R, np.float32), noise=np.zeros((R, nd), np.float32),
+             log_u=np.zeros(n, np.float32), u_res=np.zeros(n, np.float64), is_global=np.zeros(n, np.int32))
+    hio = A.StepIO(N, d, 2, nd, h["theta_prop"].ctypes.data, h["log_q"].ctypes.data, h["noise"].ctypes.data, h["log_u"].ctypes.data,
+                   h["u_res"].ctypes.data, h["is_global"].ctypes.data, None, None, None, None, None, None)
+    hrun, keep = oracle_lib.make_run(seed=seed, step0=3, n_steps=1, gf=0.6, batch=N)
+    assert oracle.oracle_propose(A.ALGO_GLMCMC, None, None, C.byref(hcs), C.byref(hrun), C.byref(hio)) == 0
+    assert np.array_equal(bits(got[G:-G].reshape(R, nd)), bits(h["noise"]))
+    assert np.array_equal(buf["is_global"].cpu().numpy(), h["is_global"])
+    assert np.array_equal(buf["u_res"].cpu().numpy(), h["u_res"])

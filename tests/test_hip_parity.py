@@ -225,6 +225,83 @@ def test_lanes_per_chain_is_only_geometry(hip, oracle, N, lanes):
     assert hc.n_moves.sum() > 0
 
 
+TEAM_CASES = [
+    # d, N, gf, eps, local, global, chains, T
+    (2, 5, 0.9, 0.05, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1]), 1000, 300),       # the bench configuration
+    (2, 2, 0.75, 0.2, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0.1, -0.1], [1.0, 1.25]), 333, 120),
+    (2, 3, 0.75, 0.2, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0.1, -0.1], [1.0, 1.25]), 64, 120),
+    (2, 4, 1.0, 0.3, ("uniform", [-0.5, -0.5], [0.5, 0.5]), ("uniform", [-3, -3], [3, 3]), 130, 150),
+    (2, 6, 0.0, 0.3, ("gauss", [0, 0], [0.5, 0.5]), ("gauss", [0, 0], [1, 1]), 65, 100),
+    (2, 8, 0.8, 0.2, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1]), 512, 150),
+    (2, 13, 0.8, 0.2, ("gauss", [0, 0], [0.35, 0.35]), ("uniform", [-3, -3], [3, 3]), 200, 100),
+    (2, 16, 0.8, 0.2, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1]), 1, 100),
+    (1, 5, 0.7, 0.3, ("gauss", [0], [0.4]), ("gauss", [0], [1]), 300, 150),
+    (3, 5, 0.7, 0.3, ("gauss", [0, 0, 0], [0.4, 0.3, 0.2]), ("gauss", [0, 0, 0], [1, 1, 1]), 300, 150),
+    (3, 7, 0.7, 0.3, ("uniform", [-0.4] * 3, [0.4] * 3), ("gauss", [0.1, 0, -0.1], [1.2, 0.9, 1]), 129, 100),
+    (4, 5, 0.7, 0.3, ("gauss", [0] * 4, [0.3] * 4), ("gauss", [0] * 4, [1] * 4), 300, 150),
+    (4, 12, 0.7, 0.3, ("gauss", [0] * 4, [0.3] * 4), ("uniform", [-3] * 4, [3] * 4), 100, 80),
+]
+
+
+@pytest.mark.parametrize("waves", [2, 3, 4])
+@pytest.mark.parametrize("case", TEAM_CASES, ids=lambda c: "d%d-N%d-gf%g-%s" % (c[0], c[1], c[2], c[5][0]))
+def test_team_geometry_is_only_geometry(hip, oracle, case, waves, monkeypatch):
+    """glabc_team.h: two to four wavefronts per 64 chains -- one keeps the chains and decides, the others evaluate candidates
+    one iteration ahead -- forced with GLABC_DEBUG_TEAM (GLABC_TEAM_WAVES picks the team size; the library falls back to a
+    smaller team when the batch cannot be split that far): histories, states, counters and sums equal the CPU checker's, and
+    with them sampler_kernel's, bit for bit; several launches, ragged last workgroup, chain id offset."""
+    monkeypatch.setenv("GLABC_TEAM_WAVES", str(waves))
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import distribution
+    d, N, gf, eps, lspec, gspec, n, T = case
+    if d == 2:
+        model, local, glob = descriptors(dict(epsilon=eps, local=lspec, **{"global": gspec}))
+    else:
+        prior = distribution.DiagGaussian(d, torch.zeros(d), torch.zeros(d)).descriptor()
+        noise = distribution.DiagGaussian(d, torch.zeros(d), torch.log(torch.full((d,), 0.05).sqrt())).descriptor()
+        kern = distribution.DiagGaussian(1, torch.tensor([0.0]), torch.log(torch.tensor([eps]))).descriptor()
+        model = A.Model()
+        model.sim_kind, model.theta_dim, model.y_dim = A.SIM_ABS_GAUSS, d, d
+        model.prior, model.noise = prior, noise
+        for j in range(d):
+            model.y_obs[j] = 1.5 - 0.25 * j
+        model.kern_log_scale, model.kern_scale, model.kern_c0, model.epsilon = kern.p1[0], kern.p2[0], kern.c0, eps
+        local, glob = make_dist(lspec).descriptor(), make_dist(gspec).descriptor()
+    rng = np.random.default_rng(31 * N + d)
+    theta0 = rng.standard_normal((n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    hist, chains, mom = hip_run("glmcmc", model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True,
+                                steps_per_launch=41, debug_flags=A.DEBUG_TEAM)
+    hh, hc, hm = oracle_run(oracle, "glmcmc", model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True)
+    same = bits(hist) == bits(hh)
+    assert same.all(), "first mismatch at (t, dim, chain) = %s" % (np.argwhere(~same)[0],)
+    assert_same_state(chains, hc, True)
+    assert np.array_equal(mom.sum_theta.cpu().numpy(), hm.sum_theta)
+    assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
+    assert hc.n_moves.sum() > 0
+    if waves == 2:          # and the one-wavefront kernel, forced the other way
+        hist1, chains1, _ = hip_run("glmcmc", model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0,
+                                    steps_per_launch=41, debug_flags=A.DEBUG_NO_TEAM)
+        assert np.array_equal(bits(hist1), bits(hist))
+
+
+@pytest.mark.parametrize("name", [n for n in SAMPLER_GOLDENS if "philox" in n and "glmcmc" in n])
+def test_team_reproduces_reference_chains(hip, name):
+    """The reference's golden chains through the team geometry (where the configuration has one: batch size 2 .. 16)."""
+    from glabcmcmc_amd import _capi as A
+    g = load_golden(name)
+    cfg = g["cfg"]
+    if not 2 <= cfg["N"] <= 16:
+        pytest.skip("no team kernel for this batch size")
+    model, local, glob = descriptors(cfg, g)
+    hist, chains, _ = hip_run(str(g["algo"]), model, local, glob, g["theta0"], g["y0"], cfg["T"], cfg["seed"],
+                              cfg["gf"], cfg["N"], chain0=cfg.get("chain0", 0), debug_flags=A.DEBUG_TEAM)
+    got = np.concatenate([g["theta0"][None], hist.transpose(0, 2, 1)], axis=0)
+    same = bits(got) == bits(g["chains"])
+    assert same.all(), "first mismatch at (t, chain, dim) = %s" % (np.argwhere(~same)[0],)
+
+
 @pytest.mark.parametrize("d,N", [(1, 5), (3, 5), (4, 5), (5, 5), (6, 3), (7, 16), (8, 5), (8, 16), (5, 1), (8, 2)])
 def test_other_dimensions(hip, oracle, d, N):
     """theta_dim 1 .. 8 (the Model is |theta| + noise in any dimension; 5 .. 8 are the default-schedule objects)."""
@@ -608,6 +685,12 @@ def test_checkpoint_resume_is_exact(hip, tmp_path):
     assert np.array_equal(bits(hist2.cpu().numpy()), bits(full[T1:]))
     assert np.array_equal(c2.theta64.cpu().numpy(), cfull.theta64.cpu().numpy())
     assert np.array_equal(c2.grad.cpu().numpy(), cfull.grad.cpu().numpy())
+    # a checkpoint written on another random-stream layout is refused, not silently continued on a different stream
+    state = torch.load(str(tmp_path / "ck2.pt"), weights_only=True)
+    state["stream_layout"] = 1
+    torch.save(state, str(tmp_path / "old.pt"))
+    with pytest.raises(RuntimeError, match="random-stream layout"):
+        checkpoint.load(str(tmp_path / "old.pt"), dev)
 
 
 def test_global_frequency_sweep(hip):

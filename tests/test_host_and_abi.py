@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), name
     h.glabc_version.restype = C.c_int
-    assert h.glabc_version() == 100
+    assert h.glabc_version() == 300 == _capi.VERSION and h.glabc_stream_layout() == _capi.STREAM_LAYOUT
     h.glabc_status_string.restype = C.c_char_p
     assert h.glabc_status_string(0) == b"ok"
 
@@ -220,3 +220,16 @@ def test_integration_stub_matches_the_abi():
         stub, real = ns[name], getattr(_capi, name)
         assert C.sizeof(stub) == C.sizeof(real), name
         assert [f[0] for f in stub._fields_] == [f[0] for f in real._fields_], name
+
+
+def test_callback_noise_streams_differ_between_shards():
+    """Every rank of a sharded run gets the same seed and its own chain0; the torch generator that draws a callback Model's
+    simulator noise (pool rows, MALA gradient estimates) is seeded with both, so shards do not share noise -- and one shard
+    (chain0 = 0) keeps the seed's own stream."""
+    import inspect
+    from glabcmcmc_amd import generic
+    seeds = {generic._noise_seed(7, c0) for c0 in (0, 1, 64, 65536, 2 ** 40)}
+    assert len(seeds) == 5 and generic._noise_seed(7, 0) == 7
+    assert all(0 <= s < 2 ** 63 for s in seeds)
+    src = inspect.getsource(generic)
+    assert src.count("manual_seed(_noise_seed(") == 2 and "manual_seed(key &" not in src and "manual_seed(self.key &" not in src

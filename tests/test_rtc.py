@@ -263,6 +263,13 @@ def test_hip_self_check_refuses_a_miscompiled_kernel(hip, monkeypatch):
         assert "disagrees with the split-phase path" in str(e)
     else:
         pytest.skip("this toolchain compiles the configuration correctly with the SLP vectorizer on")
+    # the verdict sticks: a second request (a caught exception, a re-run notebook cell) must not get the miscompiled kernel
+    with pytest.raises(SimulatorSelfCheckError):
+        cm.program(A.ALGO_GLMCMC, 12)
+    assert (A.ALGO_GLMCMC, 12) not in cm._programs
+    with pytest.raises(SimulatorSelfCheckError):
+        g_.GLMCMC(cm, 5, torch.zeros(8, 3), torch.zeros(8, 2), make_dist(("gauss", [0, 0, 0], [0.3, 0.3, 0.3])), None, 0.5,
+                  prior, 12, seed=1, verbose=False)
     monkeypatch.delenv("GLABC_RTC_OPTS")
     cm2 = g_.CompiledModel(3, 2, NONLINEAR, prior, [0.9, 0.6], 0.15, noise_dim=4)
     assert cm2.program(A.ALGO_GLMCMC, 12)                                  # the library's own options: checked and accepted
