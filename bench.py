@@ -44,6 +44,11 @@ def descriptors(workload="glmcmc"):
         lp = distribution.DiagGaussian(4, torch.zeros(1, 4), torch.log(torch.tensor([0.15, 0.1, 0.2, 0.1]))).descriptor()
         ip = distribution.Uniform(4, torch.zeros(4), torch.full((4,), 10.0)).descriptor()
         return model, lp, ip
+    if workload == "gamma":         # Gamma (distribution.py:90-137) as importance proposal AND prior of the fused kernel
+        model = Mixture_set(EPS, prior=distribution.Gamma(torch.tensor([2.0, 2.0]), torch.tensor([1.0, 1.0]))).descriptor()
+        lp = distribution.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35]))).descriptor()
+        ip = distribution.Gamma(torch.tensor([4.0, 4.0]), torch.tensor([3.0, 3.0])).descriptor()
+        return model, lp, ip
     model = Mixture_set(EPS).descriptor()
     lp = distribution.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.35, 0.35]))).descriptor()
     ip = distribution.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0])).descriptor()
@@ -580,7 +585,7 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the multi-rank control flow on ONE GPU: every rank uses cuda:0 and the collectives "
                          "run on gloo with CPU copies (numbers are meaningless; RCCL needs one GPU per rank)")
-    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback", "glmcmc_nf", "aglmcmc", "rtc", "nf_train"],
+    ap.add_argument("--workload", default="glmcmc", choices=["glmcmc", "globalmcmc", "glmala", "nf", "gk", "kde", "callback", "glmcmc_nf", "aglmcmc", "rtc", "nf_train", "gamma"],
                     help="glmcmc = BASELINE configs[1] (the headline metric, default); globalmcmc = configs[0]'s "
                          "algorithm batched (gf 0.5); glmala = configs[2] (gf 0.8, N 5, tau 0.3, num_grad 100)")
     args = ap.parse_args()
@@ -633,8 +638,8 @@ def main():
         torch.manual_seed(1234 + rank)
         y0 = GK_set(0.6).generate_samples(theta0)
     else:
-        theta0 = torch.zeros(n, D)
-        y0 = (0.05 ** 0.5) * torch.randn(n, D, generator=g)
+        theta0 = torch.full((n, D), 1.4) if args.workload == "gamma" else torch.zeros(n, D)     # inside the Gamma prior's support
+        y0 = theta0.abs() + (0.05 ** 0.5) * torch.randn(n, D, generator=g)
     chains = engine.ChainBatch(theta0, y0, dev, chain0=rank * n)
     engine.init_weights(model, ip, chains)
     hist = None if args.no_history else torch.empty(K, Dw, n, dtype=torch.float32, device=dev)
@@ -643,7 +648,7 @@ def main():
     step_idx = [0]
 
     from glabcmcmc_amd import _capi
-    gf = {"glmcmc": GF, "globalmcmc": 0.5, "glmala": 0.8, "gk": 0.9}[args.workload]
+    gf = {"glmcmc": GF, "globalmcmc": 0.5, "glmala": 0.8, "gk": 0.9, "gamma": 0.9}[args.workload]
     mala = _capi.Mala(0.3, 0.3 ** 2, EPS ** 2, 100, 0)                  # README.md:128
     if args.workload == "glmala":
         chains.add_mala_state()
@@ -759,14 +764,16 @@ def main():
                                     "glmala": "GLMALA iSIR N=5 gf=0.8 tau=0.3 num_grad=100, Mixture_set eps=0.05 d=2 "
                                               "(BASELINE configs[2])",
                                     "gk": "GLMCMC iSIR N=5 gf=0.9 on the g-and-k model (theta_dim 4, y_dim 8, eps 0.6), "
-                                          "chains sharded over the GPUs (BASELINE configs[3])"}[args.workload],
-                       "chains_per_gpu": n, "iters_per_step": K, "batch_size": args.batch if args.workload in ("glmcmc", "gk") else NBATCH,
+                                          "chains sharded over the GPUs (BASELINE configs[3])",
+                                    "gamma": "GLMCMC iSIR N=%d gf=0.9, Mixture_set eps=0.05 d=2 with a Gamma(2,1) prior and a "
+                                             "Gamma(4,3) importance proposal (distribution.py:90-137) in the fused kernel" % args.batch}[args.workload],
+                       "chains_per_gpu": n, "iters_per_step": K, "batch_size": args.batch if args.workload in ("glmcmc", "gk", "gamma") else NBATCH,
                        "history": not args.no_history,
                        "lanes_per_chain": args.lanes or "auto",
                        "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "esjd_mean": float(esjd_all[ok].double().mean()), "esjd_nan_frac": float(1.0 - ok.double().mean()),
             "mean_theta": stats["mean"], "mean_theta_sq": stats["mean_sq"],
-            "analytic": {"mean_theta": 0.0, "mean_theta_sq": 2.081014} if args.workload != "gk" else None,
+            "analytic": {"mean_theta": 0.0, "mean_theta_sq": 2.081014} if args.workload not in ("gk", "gamma") else None,
             "moment_iters": steps_all,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -774,7 +781,8 @@ def main():
                                     else "glabc::wide_kernel<D=2, L> N=%d" % args.batch,
                                     "globalmcmc": "glabc::sampler_kernel<GLOBAL, D=2, N=1>",
                                     "glmala": "glabc::glmala_kernel<D=2, N=5>",
-                                    "gk": "glabc::sampler_kernel<GLMCMC, D=4, YD=8, N=5>"}[args.workload], "kernel_ms": kernel_ms,
+                                    "gk": "glabc::sampler_kernel<GLMCMC, D=4, YD=8, N=5>",
+                                    "gamma": "glabc::sampler_kernel<GLMCMC, D=2, N=%d, VAR_GAMMA>" % args.batch}[args.workload], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_chain_step": algo_bytes / (n * K),
                          "valu": valu,
@@ -783,7 +791,9 @@ def main():
                                   "globalmcmc": "VALU-bound like the GLMCMC step (one candidate per iteration); see DESIGN.md 4.1",
                                   "glmala": "VALU-bound: a MALA move costs 400 simulations for its finite-difference gradient "
                                             "(~14 000 vector instructions per chain-step on average); see DESIGN.md 4.1b",
-                                  "gk": "VALU-bound: 8 g-and-k variates (exp, tanh, pow) + a sort per candidate; see DESIGN.md"}[args.workload]},
+                                  "gk": "VALU-bound: 8 g-and-k variates (exp, tanh, pow) + a sort per candidate; see DESIGN.md",
+                                  "gamma": "VALU-bound, float64: per candidate two Marsaglia-Tsang rejection loops (double log / sqrt) and four "
+                                           "double-precision log(pdf) evaluations; see DESIGN.md"}[args.workload]},
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "glmcmc":
             out["cpu_baseline"] = cpu_baseline()

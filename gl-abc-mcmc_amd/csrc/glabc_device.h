@@ -48,7 +48,9 @@ enum Algo { ALGO_GLMCMC = 0, ALGO_GLOBAL = 1 };
 // which removes every branch from a candidate's evaluation so the scheduler can interleave
 // the independent candidates of a lane.
 // VAR_TAPE = VAR_GENERIC with the random numbers replayed from glabc_run.tape instead of Philox (one lane per chain).
-enum Variant { VAR_GENERIC = 0, VAR_GAUSS_UNIT = 1, VAR_TAPE = 2 };
+// VAR_GAMMA = VAR_GENERIC that also knows GLABC_DIST_GAMMA as the global / importance proposal and as the prior (one lane per
+// chain): its float64 log-density and Marsaglia-Tsang loop stay out of the other instantiations' register budgets.
+enum Variant { VAR_GENERIC = 0, VAR_GAUSS_UNIT = 1, VAR_TAPE = 2, VAR_GAMMA = 3 };
 
 // ---- argument block ------------------------------------------------------------
 template <int D>
@@ -58,6 +60,7 @@ struct DistArgs {
                                  // (z-loc)/1 == z-loc and 0 + 0.5 e^2 == 0.5 e^2, bit for bit
     float c0;
     float p0[D], p1[D], p2[D];
+    float p3[D];                 // Gamma: gammaln(shape) (glabc_dist.p3)
 };
 
 template <int D, int YD = D>
@@ -243,11 +246,90 @@ GLABC_DEV float aten_rowsum_rt(F x, int n)
     return fa;
 }
 
+// ATen's float64 row sum: the float32 scheme of aten_rowsum with 4-wide vectors (probed)
+template <int N>
+GLABC_DEV double aten_rowsum_f64(const double (&x)[N])
+{
+    if constexpr (N < 4) {
+        double s = x[0];
+#pragma unroll
+        for (int i = 1; i < N; ++i) s = s + x[i];
+        return s;
+    } else {
+        constexpr int NV = N / 4;
+        constexpr int G = NV / 4;
+        double acc[4];
+        if constexpr (G == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[k] = x[k];
+#pragma unroll
+                for (int v = 1; v < NV; ++v) acc[k] = acc[k] + x[4 * v + k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) l[q] = x[4 * q + k];
+#pragma unroll
+                for (int i = 1; i < G; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) l[q] = l[q] + x[4 * (4 * i + q) + k];
+#pragma unroll
+                for (int v = 4 * G; v < NV; ++v) l[0] = l[0] + x[4 * v + k];
+                acc[k] = ((l[0] + l[1]) + l[2]) + l[3];
+            }
+        }
+        double fa = 0.0;
+#pragma unroll
+        for (int i = 4 * NV; i < N; ++i) fa = fa + x[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fa = fa + acc[k];
+        return fa;
+    }
+}
+
 // ---- distribution.py ---------------------------------------------------------------
 // DiagGaussian.log_prob, distribution.py:176-181 / Uniform.log_prob, distribution.py:81-86
-template <int D, bool KNOWN_GAUSS_UNIT = false>
+// Gamma.log_prob (distribution.py:123-137) at a float32 point: float64 per coordinate, torch.sum's float64 order, rounded once
+template <int D>
+GLABC_DEV float dist_log_prob_gamma(const DistArgs<D>& g, const float (&z)[D])
+{
+    double t[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) t[j] = glabc_gamma_log_pdf((double)g.p0[j], (double)g.p2[j], (double)g.p3[j], (double)z[j]);
+    return (float)aten_rowsum_f64<D>(t);
+}
+
+// Gamma.forward (distribution.py:106-121) for candidate j of (chain, step): theta' = (float) z, log q' = (float) log_prob(z) of
+// the DOUBLE variate z (include/glabc.h)
+template <int D>
+GLABC_DEV void dist_gamma_forward(const DistArgs<D>& g, uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t step, int j,
+                                  float (&th)[D], float& lq)
+{
+    double t[D];
+#pragma unroll 1
+    for (int q = 0; q < D; ++q) {
+        const double z = glabc_gamma_draw_candidate((double)g.p0[q], c0, c1, step, j, q, k0, k1) * (double)g.p2[q];
+        const double lp = glabc_gamma_log_pdf((double)g.p0[q], (double)g.p2[q], (double)g.p3[q], z);
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            if (r == q) {
+                th[r] = (float)z;
+                t[r] = lp;
+            }
+        }
+    }
+    lq = (float)aten_rowsum_f64<D>(t);
+}
+
+template <int D, bool KNOWN_GAUSS_UNIT = false, bool GAMMA_OK = false>
 GLABC_DEV float dist_log_prob(const DistArgs<D>& g, const float (&z)[D])
 {
+    if constexpr (GAMMA_OK) {
+        if (g.kind == GLABC_DIST_GAMMA) return dist_log_prob_gamma<D>(g, z);
+    }
     if (KNOWN_GAUSS_UNIT || g.kind == GLABC_DIST_DIAG_GAUSS) {
         float t[D];
         if (KNOWN_GAUSS_UNIT || g.unit_scale) {
@@ -464,12 +546,12 @@ struct Chain {
     uint32_t n_moves;
 };
 
-template <int D, int YD>
+template <int D, int YD, bool GAMMA_OK = false>
 GLABC_DEV void refresh_cache(const StepArgs<D, YD>& a, Chain<D, YD>& c)
 {
-    c.prior = dist_log_prob<D>(a.prior, c.theta);
+    c.prior = dist_log_prob<D, false, GAMMA_OK>(a.prior, c.theta);
     c.kern = model_log_kernel<D, YD>(a, c.y);
-    c.q = dist_log_prob<D>(a.global, c.theta);
+    c.q = dist_log_prob<D, false, GAMMA_OK>(a.global, c.theta);
 }
 
 // One iteration of GLMCMC (GLMCMC.py:58-104) or GlobalMCMC (GlobalMCMC.py:37-68) for the
@@ -490,7 +572,9 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
 {
     constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
     constexpr bool TAPE = (VAR == VAR_TAPE);
+    constexpr bool GM = (VAR == VAR_GAMMA);
     static_assert(!TAPE || L == 1, "tape replay runs one lane per chain");
+    static_assert(!GM || L == 1, "the Gamma variant runs one lane per chain");
     constexpr int NL = (N + L - 1) / L;            // candidate slots per lane
     constexpr int HEAD = L - 1;                    // the lane with the fewest candidates draws the step head
     // When N is not a multiple of L the last slot of lane L-1 holds no candidate: the step head
@@ -587,6 +671,18 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
             const float t = p0 + p2 * e[q];                                   // distribution.py:170 / :77
             th[r][q] = loc ? (t + c.theta[q]) : t;                            // GLMCMC.py:91
         }
+        // a Gamma importance / global proposal (wave-uniform): the candidate and forward()'s log q from the chain's Gamma
+        // slots; the lanes on the local branch keep candidate 0 as built above
+        float lq_gamma = 0.0f;
+        const bool g_gam = GM && a.global.kind == GLABC_DIST_GAMMA;
+        if constexpr (GM) {
+            if (g_gam) {
+                float tg[D];
+                dist_gamma_forward<D>(a.global, rng.c0, rng.c1, rng.k0, rng.k1, step, j, tg, lq_gamma);
+#pragma unroll
+                for (int q = 0; q < D; ++q) th[r][q] = loc ? th[r][q] : tg[q];
+            }
+        }
         // log q of the proposal under the global distribution: from its noise (forward(), GLMCMC.py:66) for an iSIR
         // candidate; for GLMCMC's local move q(theta') itself, so that lw / wl of slot 0 are the log-weight and weight
         // the proposed state will carry if it is accepted (what GLMCMC.py:60-64 computes at the next global step)
@@ -597,12 +693,12 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
             for (int q = 0; q < D; ++q) v[q] = loc ? (th[r][q] - a.global.p0[q]) : e[q];
             lq = dist_forward_log_p<D, GU>(a.global, v);
         } else if constexpr (ALGO == ALGO_GLMCMC) {
-            lq = loc ? dist_log_prob<D, GU>(a.global, th[r]) : dist_forward_log_p<D, GU>(a.global, e);
+            lq = loc ? dist_log_prob<D, GU, GM>(a.global, th[r]) : (g_gam ? lq_gamma : dist_forward_log_p<D, GU>(a.global, e));
         } else {
-            lq = dist_forward_log_p<D, GU>(a.global, e);                      // unused by the local move
+            lq = g_gam ? lq_gamma : dist_forward_log_p<D, GU>(a.global, e);   // unused by the local move
         }
         model_simulate<D, YD>(a, th[r], s, yy[r]);
-        pr[r] = dist_log_prob<D, GU>(a.prior, th[r]);
+        pr[r] = dist_log_prob<D, GU, GM>(a.prior, th[r]);
         kk[r] = model_log_kernel<D, YD, GU>(a, yy[r]);
         const float pk = pr[r] + kk[r];
         lw[r] = pk - lq;                                                      // GLMCMC.py:74
@@ -707,7 +803,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
             for (int q = 0; q < YD; ++q) c.y[q] = ny[q];
             c.prior = npr;
             c.kern = nkk;
-            c.q = dist_log_prob<D, GU>(a.global, c.theta);
+            c.q = dist_log_prob<D, GU, GM>(a.global, c.theta);
             if (ALGO == ALGO_GLMCMC) {
                 c.lw_cur = nlw;
                 c.w_cur = nw;

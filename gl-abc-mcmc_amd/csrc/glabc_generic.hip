@@ -33,12 +33,42 @@ struct GenDist {
     int32_t present;             // 0: the caller fills this proposal's rows itself
     int32_t kind, dim;
     float c0;
-    float p0[GD], p1[GD], p2[GD];
+    float p0[GD], p1[GD], p2[GD], p3[GD];
 };
 
-// DiagGaussian.log_prob / Uniform.log_prob (distribution.py:176-181, 81-86) at a point held in registers
+// torch.sum over a short float64 register row t[0..n), n <= 8: aten_rowsum_f64<N> (glabc_device.h) spelled with predicates
+GLABC_DEV double rowsum_small_f64(const double (&t)[GD], int n)
+{
+    if (n < 4) {
+        double s = t[0];
+        if (n > 1) s = s + t[1];
+        if (n > 2) s = s + t[2];
+        return s;
+    }
+    double acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = (n == 8) ? t[k] + t[4 + k] : t[k];
+    double fa = 0.0;
+    if (n < 8) {
+#pragma unroll
+        for (int i = 4; i < 8; ++i)
+            if (i < n) fa = fa + t[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fa = fa + acc[k];
+    return fa;
+}
+
+// DiagGaussian.log_prob / Uniform.log_prob / Gamma.log_prob (distribution.py:176-181, 81-86, 123-137) at a point held in registers
 GLABC_DEV float gen_log_prob(const GenDist& g, const float (&z)[GD])
 {
+    if (g.kind == GLABC_DIST_GAMMA) {                                  // float64 per coordinate, rounded once (include/glabc.h)
+        double t[GD];
+#pragma unroll
+        for (int j = 0; j < GD; ++j)
+            t[j] = j < g.dim ? glabc_gamma_log_pdf((double)g.p0[j], (double)g.p2[j], (double)g.p3[j], (double)z[j]) : 0.0;
+        return (float)rowsum_small_f64(t, g.dim);
+    }
     if (g.kind == GLABC_DIST_DIAG_GAUSS) {
         float t[GD];
 #pragma unroll
@@ -166,6 +196,21 @@ __global__ void __launch_bounds__(256) propose_kernel(const GenArgs a)
     }
     if (!g.present) return;                                                 // the caller fills this proposal's rows
     float* th_out = a.theta_prop + r * D;
+    if (is_global && g.kind == GLABC_DIST_GAMMA) {                          // Gamma.forward on the chain's Gamma slots (include/glabc.h)
+        double t[GD];
+#pragma unroll
+        for (int q = 0; q < GD; ++q) t[q] = 0.0;
+        for (int q = 0; q < g.dim; ++q) {
+            const double z = glabc_gamma_draw_candidate((double)g.p0[q], c0, c1, step, j, q, a.seed_lo, a.seed_hi) * (double)g.p2[q];
+            th_out[q] = (float)z;
+            const double lp = glabc_gamma_log_pdf((double)g.p0[q], (double)g.p2[q], (double)g.p3[q], z);
+#pragma unroll
+            for (int k = 0; k < GD; ++k)
+                if (k == q) t[k] = lp;
+        }
+        a.log_q[r] = (float)rowsum_small_f64(t, g.dim);
+        return;
+    }
     if (is_global) {
         apply_proposal(g, e, nullptr, 0, th_out, a.log_q + r);              // GLMCMC.py:66 / GlobalMCMC.py:40
     } else {
@@ -365,24 +410,29 @@ using namespace glabc;
 
 static int finish() { return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH; }
 
-static int pack_gen_dist(const glabc_dist* g, int dim, GenDist* o)
+// allow_gamma: the global / importance proposal may be a Gamma (include/glabc.h); the local increment may not
+static int pack_gen_dist(const glabc_dist* g, int dim, GenDist* o, bool allow_gamma)
 {
     std::memset(o, 0, sizeof *o);
     if (!g) return GLABC_OK;
     if (g->dim != dim || dim < 1 || dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
-    if (g->kind != GLABC_DIST_DIAG_GAUSS && g->kind != GLABC_DIST_UNIFORM) return GLABC_ERR_KIND;
+    const bool gamma = g->kind == GLABC_DIST_GAMMA;
+    if (g->kind != GLABC_DIST_DIAG_GAUSS && g->kind != GLABC_DIST_UNIFORM && !(gamma && allow_gamma)) return GLABC_ERR_KIND;
     o->present = 1;
     o->kind = g->kind;
     o->dim = g->dim;
-    o->c0 = g->c0;
-    if (!std::isfinite(g->c0)) return GLABC_ERR_ARG;
+    o->c0 = gamma ? 0.0f : g->c0;
+    if (!gamma && !std::isfinite(g->c0)) return GLABC_ERR_ARG;
     for (int j = 0; j < GLABC_MAX_DIM; ++j) {
         const bool in = j < dim;
         o->p0[j] = in ? g->p0[j] : 0.0f;
         o->p1[j] = in ? g->p1[j] : 0.0f;
         o->p2[j] = in ? g->p2[j] : 1.0f;
+        o->p3[j] = (in && gamma) ? g->p3[j] : 0.0f;
         if (in && (!std::isfinite(g->p0[j]) || !std::isfinite(g->p1[j]) || !std::isfinite(g->p2[j]))) return GLABC_ERR_ARG;
         if (in && g->kind == GLABC_DIST_DIAG_GAUSS && !(g->p2[j] > 0.0f)) return GLABC_ERR_ARG;
+        if (in && gamma && (!(g->p0[j] > 0.0f) || !(g->p1[j] > 0.0f) || !(g->p2[j] > 0.0f) || !std::isfinite(g->p3[j])))
+            return GLABC_ERR_ARG;                                       // shape, rate, scale > 0; gammaln(shape) finite
     }
     return GLABC_OK;
 }
@@ -400,9 +450,9 @@ static int pack_common(int algo, const glabc_dist* local, const glabc_dist* glob
     if (!c->theta || !c->y) return GLABC_ERR_NULL;
     if (!(r->global_frequency >= 0.0f) && !(r->global_frequency < 0.0f)) return GLABC_ERR_ARG;
     std::memset(a, 0, sizeof *a);
-    int rc = pack_gen_dist(local, io->theta_dim, &a->local);
+    int rc = pack_gen_dist(local, io->theta_dim, &a->local, false);
     if (rc) return rc;
-    rc = pack_gen_dist(global, io->theta_dim, &a->global);
+    rc = pack_gen_dist(global, io->theta_dim, &a->global, true);
     if (rc) return rc;
     a->algo = algo;
     a->n_prop = io->n_prop;

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(BLOCK) init_weights_kernel(const StepArgs<D, Y
     for (int j = 0; j < D; ++j) c.theta[j] = a.theta[j * a.stride + i];
 #pragma unroll
     for (int j = 0; j < YD; ++j) c.y[j] = a.y[j * a.stride + i];
-    refresh_cache<D, YD>(a, c);
+    refresh_cache<D, YD, true>(a, c);                              // Gamma importance proposal / prior included
     a.log_w[i] = (c.prior + c.kern) - c.q;                         // GLMCMC.py:52-55
     a.flags[i] = a.flags[i] | GLABC_FLAG_LOCAL;                    // GLMCMC.py:50
 }
@@ -65,6 +65,7 @@ __device__ __forceinline__ DistArgs<D> narrow(const glabc_dist& g)
         o.p0[j] = g.p0[j];
         o.p1[j] = g.p1[j];
         o.p2[j] = g.p2[j];
+        o.p3[j] = g.p3[j];
         unit = unit && (g.p2[j] == 1.0f) && (g.p1[j] == 0.0f);
     }
     o.unit_scale = unit ? 1 : 0;
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(256) rowwise_kernel(const RowArgs a)
     float r;
     if constexpr (OP == ROW_DIST_LOG_PROB || OP == ROW_PRIOR) {
         DistArgs<D> g = narrow<D>(a.dist);
-        r = dist_log_prob<D>(g, x);
+        r = dist_log_prob<D, false, true>(g, x);                   // DiagGaussian / Uniform / Gamma
     } else {
         float t[D];
 #pragma unroll
@@ -496,10 +497,20 @@ static bool finite_dist(const glabc_dist* g)
     return std::isfinite(g->c0);
 }
 
-static int check_dist(const glabc_dist* g, int dim)
+// allow_gamma: GLABC_DIST_GAMMA is known where include/glabc.h says so (importance / global proposal and prior of
+// glabc_glmcmc_steps / glabc_globalmcmc_steps / glabc_init_weights, glabc_dist_log_prob, the row-wise Model callbacks)
+static int check_dist(const glabc_dist* g, int dim, bool allow_gamma = false)
 {
     if (!g) return GLABC_ERR_NULL;
     if (g->dim < 1 || g->dim > GLABC_MAX_DIM || (dim > 0 && g->dim != dim)) return GLABC_ERR_DIM;
+    if (g->kind == GLABC_DIST_GAMMA) {
+        if (!allow_gamma) return GLABC_ERR_KIND;
+        for (int j = 0; j < g->dim; ++j)            // shape, rate, scale = 1/rate > 0 and finite; gammaln(shape) finite
+            if (!(g->p0[j] > 0.0f) || !std::isfinite(g->p0[j]) || !(g->p1[j] > 0.0f) || !std::isfinite(g->p1[j]) ||
+                !(g->p2[j] > 0.0f) || !std::isfinite(g->p2[j]) || !std::isfinite(g->p3[j]))
+                return GLABC_ERR_ARG;
+        return GLABC_OK;
+    }
     if (g->kind != GLABC_DIST_DIAG_GAUSS && g->kind != GLABC_DIST_UNIFORM) return GLABC_ERR_KIND;
     if (!finite_dist(g)) return GLABC_ERR_ARG;
     if (g->kind == GLABC_DIST_DIAG_GAUSS)
@@ -508,12 +519,12 @@ static int check_dist(const glabc_dist* g, int dim)
     return GLABC_OK;
 }
 
-static int check_model(const glabc_model* m, bool allow_user_sim = false)
+static int check_model(const glabc_model* m, bool allow_user_sim = false, bool allow_gamma_prior = false)
 {
     if (!m) return GLABC_ERR_NULL;
     if (allow_user_sim && m->sim_kind == GLABC_SIM_USER) {            // row-wise callbacks: the simulator is not involved
         if (m->theta_dim < 1 || m->theta_dim > GLABC_MAX_DIM || m->y_dim < 1 || m->y_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
-        int rc0 = check_dist(&m->prior, m->theta_dim);
+        int rc0 = check_dist(&m->prior, m->theta_dim, allow_gamma_prior);
         if (rc0) return rc0;
         if (!std::isfinite(m->kern_log_scale) || !(m->kern_scale > 0.0f) || !std::isfinite(m->kern_scale) || !std::isfinite(m->kern_c0))
             return GLABC_ERR_ARG;
@@ -523,7 +534,7 @@ static int check_model(const glabc_model* m, bool allow_user_sim = false)
     }
     if (m->sim_kind != GLABC_SIM_ABS_GAUSS && m->sim_kind != GLABC_SIM_GK) return GLABC_ERR_KIND;
     if (m->theta_dim < 1 || m->theta_dim > GLABC_MAX_DIM || m->y_dim < 1 || m->y_dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
-    int rc = check_dist(&m->prior, m->theta_dim);
+    int rc = check_dist(&m->prior, m->theta_dim, allow_gamma_prior);
     if (rc) return rc;
     if (m->sim_kind == GLABC_SIM_GK) {
         if (m->theta_dim != 4 || m->y_dim != 8) return GLABC_ERR_DIM;          // the compiled g-and-k shape
@@ -600,12 +611,15 @@ static unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 static int check_run(const glabc_model* m, const glabc_dist* local, const glabc_dist* global, const glabc_chains* c,
                      const glabc_run* r, bool isir)
 {
-    int rc = check_model(m);
+    int rc = check_model(m, false, true);
     if (rc) return rc;
     rc = check_dist(local, m->theta_dim);
     if (rc) return rc;
-    rc = check_dist(global, m->theta_dim);
+    rc = check_dist(global, m->theta_dim, true);
     if (rc) return rc;
+    const bool gamma = m->prior.kind == GLABC_DIST_GAMMA || global->kind == GLABC_DIST_GAMMA;
+    if (gamma && (m->sim_kind != GLABC_SIM_ABS_GAUSS || m->theta_dim > 4)) return GLABC_ERR_KIND;    // the instantiated Gamma variants
+    if (gamma && r && r->tape) return GLABC_ERR_ARG;                // a tape has no Gamma variates
     if (!c || !r) return GLABC_ERR_NULL;
     if (!c->theta || !c->y) return GLABC_ERR_NULL;
     if (isir && (!c->log_w || !c->flags)) return GLABC_ERR_NULL;
@@ -668,7 +682,8 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
     }
     // Team geometry (glabc_team.h): two wavefronts per 64 chains, for launches that would otherwise leave the SIMDs with at most
     // two wavefronts of sampler_kernel each.  Chosen when the caller leaves the geometry to the library.
-    if (algo == ALGO_GLMCMC && !r->tape && !(r->debug_flags & GLABC_DEBUG_NO_TEAM) &&
+    const bool gamma = m->prior.kind == GLABC_DIST_GAMMA || global->kind == GLABC_DIST_GAMMA;      // VAR_GAMMA: one lane per chain
+    if (algo == ALGO_GLMCMC && !r->tape && !gamma && !(r->debug_flags & GLABC_DEBUG_NO_TEAM) &&
         ((r->debug_flags & GLABC_DEBUG_TEAM) || (r->lanes_per_chain == 0 && c->n_chains >= 64 * 256 && c->n_chains <= 2 * 1024 * 64))) {
         int prio = 1;                                       // the main wavefront carries the serial part of an iteration
         if (const char* e = std::getenv("GLABC_TEAM_PRIO")) prio = std::max(0, std::min(3, std::atoi(e)));
@@ -694,11 +709,11 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
             return rc;
         }
     }
-    const int lanes = (algo == ALGO_GLMCMC && !r->tape) ? pick_lanes(r->lanes_per_chain, r->batch_size, c->n_chains) : 1;
+    const int lanes = (algo == ALGO_GLMCMC && !r->tape && !gamma) ? pick_lanes(r->lanes_per_chain, r->batch_size, c->n_chains) : 1;
     // Two builds of the same kernels: up to two waves per SIMD (131 072 lanes on this part) a launch is latency-bound
     // and runs the max-ilp schedule (217 VGPRs, 6 % faster at 65 536 chains); larger launches need the occupancy
     // of the default schedule (126 VGPRs).  The tape variant and lane groups exist in the default objects only.
-    const bool ilp = lanes == 1 && !r->tape && c->n_chains <= 2 * 1024 * 64;
+    const bool ilp = lanes == 1 && !r->tape && !gamma && c->n_chains <= 2 * 1024 * 64;
     if (m->sim_kind == GLABC_SIM_GK) {
         rc = launch_sampler_dim<4, 8, SCHED_DEFAULT>(algo, r->batch_size, lanes, pack_args<4, 8>(m, local, global, c, r), s);
     } else {
@@ -1044,9 +1059,9 @@ __attribute__((visibility("default"))) int glabc_globalmcmc_steps(const glabc_mo
 __attribute__((visibility("default"))) int glabc_init_weights(const glabc_model* model, const glabc_dist* importance,
                                                               const glabc_chains* c, void* stream)
 {
-    int rc = check_model(model);
+    int rc = check_model(model, false, true);
     if (rc) return rc;
-    rc = check_dist(importance, model->theta_dim);
+    rc = check_dist(importance, model->theta_dim, true);
     if (rc) return rc;
     if (!c || !c->theta || !c->y || !c->log_w || !c->flags) return GLABC_ERR_NULL;
     if (c->n_chains < 0 || c->stride < c->n_chains) return GLABC_ERR_ARG;
@@ -1074,7 +1089,7 @@ __attribute__((visibility("default"))) int glabc_init_weights(const glabc_model*
 __attribute__((visibility("default"))) int glabc_dist_log_prob(const glabc_dist* dist, const float* z, int64_t n, float* out,
                                                                void* stream)
 {
-    int rc = check_dist(dist, 0);
+    int rc = check_dist(dist, 0, true);
     if (rc) return rc;
     if (!z || !out) return GLABC_ERR_NULL;
     if (n < 0) return GLABC_ERR_ARG;
@@ -1091,7 +1106,7 @@ __attribute__((visibility("default"))) int glabc_dist_log_prob(const glabc_dist*
 
 static int model_rowwise(const glabc_model* m, const float* in, int64_t n, float* out, void* stream, int op)
 {
-    int rc = check_model(m, true);
+    int rc = check_model(m, true, true);
     if (rc) return rc;
     if (!in || !out) return GLABC_ERR_NULL;
     if (n < 0) return GLABC_ERR_ARG;

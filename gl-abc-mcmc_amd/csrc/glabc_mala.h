@@ -38,50 +38,6 @@ struct MalaArgs {
     int32_t prio;                // team kernel: s_setprio of the main wavefront (it carries the serial part of an iteration)
 };
 
-// ATen's float64 row sum: the float32 scheme of aten_rowsum with 4-wide vectors (probed)
-template <int N>
-GLABC_DEV double aten_rowsum_f64(const double (&x)[N])
-{
-    if constexpr (N < 4) {
-        double s = x[0];
-#pragma unroll
-        for (int i = 1; i < N; ++i) s = s + x[i];
-        return s;
-    } else {
-        constexpr int NV = N / 4;
-        constexpr int G = NV / 4;
-        double acc[4];
-        if constexpr (G == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                acc[k] = x[k];
-#pragma unroll
-                for (int v = 1; v < NV; ++v) acc[k] = acc[k] + x[4 * v + k];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double l[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) l[q] = x[4 * q + k];
-#pragma unroll
-                for (int i = 1; i < G; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) l[q] = l[q] + x[4 * (4 * i + q) + k];
-#pragma unroll
-                for (int v = 4 * G; v < NV; ++v) l[0] = l[0] + x[4 * v + k];
-                acc[k] = ((l[0] + l[1]) + l[2]) + l[3];
-            }
-        }
-        double fa = 0.0;
-#pragma unroll
-        for (int i = 4 * NV; i < N; ++i) fa = fa + x[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fa = fa + acc[k];
-        return fa;
-    }
-}
-
 // distribution.py:176-181 / 81-86 on a float64 tensor
 template <int D>
 GLABC_DEV double dist_log_prob_f64(const DistArgs<D>& g, const double (&z)[D])

@@ -20,6 +20,7 @@ inline DistArgs<D> pack_dist(const glabc_dist* g)
         o.p0[j] = g->p0[j];
         o.p1[j] = g->p1[j];
         o.p2[j] = g->p2[j];
+        o.p3[j] = g->p3[j];
         unit = unit && (g->p2[j] == 1.0f) && (g->p1[j] == 0.0f);
     }
     o.unit_scale = unit ? 1 : 0;

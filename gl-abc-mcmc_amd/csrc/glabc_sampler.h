@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(BLOCK) sampler_kernel(const StepArgs<D, YD> a)
     c.flags = (ALGO == ALGO_GLMCMC) ? a.flags[i] : 0u;
     c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
     c.gf = a.gf_chain ? a.gf_chain[i] : a.gf;
-    refresh_cache<D, YD>(a, c);
+    refresh_cache<D, YD, VAR == VAR_GAMMA>(a, c);
     c.lw_cur = (c.flags & GLABC_FLAG_LOCAL) ? (c.prior + c.kern) - c.q : c.log_w;          // GLMCMC.py:60-64
     {
         const float v = glabc_expf(c.lw_cur);

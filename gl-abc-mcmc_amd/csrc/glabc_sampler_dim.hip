@@ -33,6 +33,15 @@ static int launch_one(const StepArgs<D, YD>& a, hipStream_t s)
             hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, 1, VAR_TAPE, GLABC_SCHED>), dim3(grid), dim3(BLOCK), 0, s, a);
         else
             return GLABC_ERR_ARG;
+    } else if (a.prior.kind == GLABC_DIST_GAMMA || a.global.kind == GLABC_DIST_GAMMA) {
+#if GLABC_SCHED == 0
+        if constexpr (L == 1 && D <= 4 && YD == D)
+            hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, 1, VAR_GAMMA, GLABC_SCHED>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else
+            return GLABC_ERR_KIND;
+#else
+        return GLABC_ERR_KIND;                                      // the Gamma variant lives in the default-schedule objects
+#endif
     } else if (YD == D && gauss_unit<D, YD>(a))
         hipLaunchKernelGGL((sampler_kernel<ALGO, D, YD, N, L, (YD == D ? VAR_GAUSS_UNIT : VAR_GENERIC), GLABC_SCHED>), dim3(grid), dim3(BLOCK), 0, s, a);
     else

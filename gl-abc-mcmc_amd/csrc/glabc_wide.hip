@@ -36,7 +36,8 @@ struct Cand {
 };
 
 // candidate j of (chain, step): the arithmetic of chain_step's generic variant for one slot
-template <int D, int YD>
+// GM: the instantiation also knows GLABC_DIST_GAMMA as importance proposal / prior (chain_step's VAR_GAMMA)
+template <int D, int YD, bool GM>
 GLABC_DEV Cand eval_candidate(const StepArgs<D, YD>& a, const Rng& rng, uint32_t step, int j, bool loc, const Chain<D, YD>& c,
                               float (&th)[D], float (&yy)[YD])
 {
@@ -63,10 +64,20 @@ GLABC_DEV Cand eval_candidate(const StepArgs<D, YD>& a, const Rng& rng, uint32_t
         const float t = p0 + p2 * e[q];                                       // distribution.py:170 / :77
         th[q] = loc ? (t + c.theta[q]) : t;                                   // GLMCMC.py:91
     }
-    const float lq = loc ? dist_log_prob<D>(a.global, th) : dist_forward_log_p<D>(a.global, e);
+    float lq_gamma = 0.0f;
+    const bool g_gam = GM && a.global.kind == GLABC_DIST_GAMMA;
+    if constexpr (GM) {
+        if (g_gam) {                                                          // wave-uniform; local-branch lanes keep theta + increment
+            float tg[D];
+            dist_gamma_forward<D>(a.global, rng.c0, rng.c1, rng.k0, rng.k1, step, j, tg, lq_gamma);
+#pragma unroll
+            for (int q = 0; q < D; ++q) th[q] = loc ? th[q] : tg[q];
+        }
+    }
+    const float lq = loc ? dist_log_prob<D, false, GM>(a.global, th) : (g_gam ? lq_gamma : dist_forward_log_p<D>(a.global, e));
     model_simulate<D, YD>(a, th, s, yy);                                      // GLMCMC.py:71,94
     Cand r;
-    r.pr = dist_log_prob<D>(a.prior, th);
+    r.pr = dist_log_prob<D, false, GM>(a.prior, th);
     r.kk = model_log_kernel<D, YD>(a, yy);
     const float pk = r.pr + r.kk;
     r.lw = pk - lq;                                                           // GLMCMC.py:74
@@ -90,7 +101,7 @@ GLABC_DEV int grp_get_i(int v, int src_sub)
     return __shfl(v, (lane & ~(L - 1)) | src_sub, 64);
 }
 
-template <int D, int YD, int L>
+template <int D, int YD, int L, bool GM>
 __global__ void __launch_bounds__(WIDE_BLOCK) wide_kernel(const StepArgs<D, YD> a, const int N)
 {
     extern __shared__ __attribute__((aligned(16))) float wide_lds[];
@@ -113,7 +124,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) wide_kernel(const StepArgs<D, YD> 
     c.flags = a.flags[i];
     c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
     c.gf = a.gf_chain ? a.gf_chain[i] : a.gf;
-    refresh_cache<D, YD>(a, c);
+    refresh_cache<D, YD, GM>(a, c);
     c.lw_cur = (c.flags & GLABC_FLAG_LOCAL) ? (c.prior + c.kern) - c.q : c.log_w;          // GLMCMC.py:60-64
     {
         const float v = glabc_expf(c.lw_cur);
@@ -169,7 +180,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) wide_kernel(const StepArgs<D, YD> 
         for (int r = 0; r < rounds; ++r) {
             const int j = is_global ? sub + L * r : 0;                  // a chain on the local branch: candidate 0, every lane
             if ((is_global && j < N) || (!is_global && r == 0)) {
-                cd = eval_candidate<D, YD>(a, rng, step, j, !is_global, c, th, yy);
+                cd = eval_candidate<D, YD, GM>(a, rng, step, j, !is_global, c, th, yy);
                 if (is_global) w[1 + j] = cd.wl;
             }
         }
@@ -260,7 +271,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) wide_kernel(const StepArgs<D, YD> 
             if (rounds_all > 1 && __any(moved && is_global)) {
                 // several candidates per lane: every lane re-evaluates the winner (same counter, same bits)
                 float th2[D], yy2[YD];
-                const Cand c2 = eval_candidate<D, YD>(a, rng, step, moved && is_global ? ind - 1 : 0, false, c, th2, yy2);
+                const Cand c2 = eval_candidate<D, YD, GM>(a, rng, step, moved && is_global ? ind - 1 : 0, false, c, th2, yy2);
                 if (moved && is_global) {
 #pragma unroll
                     for (int q = 0; q < D; ++q) th[q] = th2[q];
@@ -276,7 +287,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) wide_kernel(const StepArgs<D, YD> 
                 for (int q = 0; q < YD; ++q) c.y[q] = yy[q];
                 c.prior = cd.pr;
                 c.kern = cd.kk;
-                c.q = dist_log_prob<D>(a.global, c.theta);
+                c.q = dist_log_prob<D, false, GM>(a.global, c.theta);
                 c.lw_cur = cd.lw;
                 c.w_cur = cd.wl;
                 if (is_global)
@@ -327,16 +338,26 @@ __global__ void __launch_bounds__(WIDE_BLOCK) wide_kernel(const StepArgs<D, YD> 
     }
 }
 
-template <int D, int YD, int L>
-static int launch_wide_l(const StepArgs<D, YD>& a, int N, hipStream_t s)
+template <int D, int YD, int L, bool GM>
+static int launch_wide_lg(const StepArgs<D, YD>& a, int N, hipStream_t s)
 {
     constexpr int GROUPS = WIDE_BLOCK / L;
     const size_t lds = sizeof(float) * (size_t)GROUPS * (size_t)(N + 1 + 32);
     static LdsGrant grant;                               // per instantiation, per device
-    if (!grant_dynamic_lds(grant, (const void*)wide_kernel<D, YD, L>, lds)) return GLABC_ERR_LAUNCH;
+    if (!grant_dynamic_lds(grant, (const void*)wide_kernel<D, YD, L, GM>, lds)) return GLABC_ERR_LAUNCH;
     const unsigned grid = (unsigned)((a.n_chains + GROUPS - 1) / GROUPS);
-    hipLaunchKernelGGL((wide_kernel<D, YD, L>), dim3(grid), dim3(WIDE_BLOCK), lds, s, a, N);
+    hipLaunchKernelGGL((wide_kernel<D, YD, L, GM>), dim3(grid), dim3(WIDE_BLOCK), lds, s, a, N);
     return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
+}
+
+template <int D, int YD, int L>
+static int launch_wide_l(const StepArgs<D, YD>& a, int N, hipStream_t s)
+{
+    if (a.prior.kind == GLABC_DIST_GAMMA || a.global.kind == GLABC_DIST_GAMMA) {      // Gamma importance proposal / prior
+        if constexpr (YD == D) return launch_wide_lg<D, YD, L, true>(a, N, s);
+        else return GLABC_ERR_KIND;
+    }
+    return launch_wide_lg<D, YD, L, false>(a, N, s);
 }
 
 // lanes per chain: the smallest group that keeps a lane at no more than 8 candidates (the per-step head, total and index

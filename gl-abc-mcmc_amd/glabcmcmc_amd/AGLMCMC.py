@@ -44,6 +44,7 @@ def AGLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Initial_I
     from . import generic
     desc = generic.try_descriptor(ABCset)
     builtin = isinstance(desc, _capi.Model) and desc.sim_kind in (_capi.SIM_ABS_GAUSS, _capi.SIM_GK) and \
+        desc.prior.kind != _capi.DIST_GAMMA and \
         generic.dist_descriptor(Local_Proposal, desc.theta_dim) is not None and \
         generic.dist_descriptor(Initial_ISIR_prop, desc.theta_dim) is not None
     if path == "generic" or (path == "auto" and not builtin):

@@ -34,7 +34,7 @@ def GLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     if path not in ("auto", "fused", "generic"):
         raise ValueError("path must be 'auto', 'fused' or 'generic'")
     if path == "generic" or (path == "auto" and not generic.fused_supported(ABCset, (Local_Proposal, Importance_Proposal),
-                                                                             batch_size, _capi.MAX_BATCH_WIDE)):
+                                                                             batch_size, _capi.MAX_BATCH_WIDE, gamma_ok=True)):
         return generic.run(_capi.ALGO_GLMCMC, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Importance_Proposal,
                            filelocation, global_frequency, batch_size, "glmcmc", seed=seed, device=device, chain0=chain0,
                            record_history=record_history, stats=stats, return_device=return_device, verbose=verbose,

@@ -55,6 +55,7 @@ def GLMCMC_NF(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     from . import generic
     desc = generic.try_descriptor(ABCset)
     builtin = isinstance(desc, _capi.Model) and desc.sim_kind in (_capi.SIM_ABS_GAUSS, _capi.SIM_GK) and \
+        desc.prior.kind != _capi.DIST_GAMMA and \
         generic.dist_descriptor(Local_Proposal, desc.theta_dim) is not None
     if path == "generic" or (path == "auto" and not builtin):
         # a Model given as callbacks (or a CompiledModel): pools, local moves and weights through the Model's own methods

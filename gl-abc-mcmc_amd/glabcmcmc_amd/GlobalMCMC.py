@@ -15,7 +15,7 @@ def GlobalMCMC(ABCset, num_ite, Initial_theta, Initial_y,
         Local_Proposal = Global_Proposal
     if path not in ("auto", "fused", "generic"):
         raise ValueError("path must be 'auto', 'fused' or 'generic'")
-    if path == "generic" or (path == "auto" and not generic.fused_supported(ABCset, (Local_Proposal, Global_Proposal), 1)):
+    if path == "generic" or (path == "auto" and not generic.fused_supported(ABCset, (Local_Proposal, Global_Proposal), 1, gamma_ok=True)):
         return generic.run(_capi.ALGO_GLOBALMCMC, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_Proposal,
                            filelocation, global_frequency, 1, "global", seed=seed, device=device, chain0=chain0,
                            record_history=record_history, stats=stats, return_device=return_device, verbose=verbose,

@@ -45,6 +45,7 @@ class Dist(C.Structure):
         ("p0", _f8),
         ("p1", _f8),
         ("p2", _f8),
+        ("p3", _f8),
         ("c0", C.c_float),
     ]
 

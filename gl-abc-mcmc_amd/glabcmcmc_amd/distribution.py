@@ -139,7 +139,7 @@ class Gamma(BaseDistribution):
     def forward(self, num_samples=1, context=None, device=None, seed=None, row0=None):
         dev = self.device if device is None else torch.device(device)
         if dev is not None and dev.type == "cuda":
-            desc = self.descriptor()
+            desc = self.gamma_descriptor()
             if seed is None:
                 if self.seed is None:
                     self.seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
@@ -161,7 +161,26 @@ class Gamma(BaseDistribution):
         return z, self.log_prob(z)
 
     def descriptor(self):
-        """glabc_gamma (include/glabc.h): float64 shape, scale = 1/rate as distribution.py:133 forms it, gammaln(shape)"""
+        """glabc_dist of kind GLABC_DIST_GAMMA (include/glabc.h): what the samplers take -- Gamma as the importance / global
+        proposal or as a Model's prior inside the fused kernels and glabc_propose / glabc_select.  p0 = shape, p1 = rate,
+        p2 = 1/rate as distribution.py:118,133 forms it (float32 division), p3 = scipy.special.gammaln(shape) in the dtype of
+        the float32 Shape array (distribution.py:103)."""
+        from scipy.special import gammaln
+        shape = np.asarray(self.Shape, dtype=np.float32).reshape(-1)
+        rate = np.asarray(self.Rate, dtype=np.float32).reshape(-1)
+        scale = (np.float32(1) / rate).astype(np.float32)
+        gl = np.asarray(gammaln(shape), dtype=np.float32).reshape(-1)
+        if shape.size > _capi.MAX_DIM or rate.size != shape.size:
+            raise ValueError("Gamma descriptor: 1..%d coordinates with one shape and one rate each" % _capi.MAX_DIM)
+        d = _capi.Dist()
+        d.kind, d.dim = _capi.DIST_GAMMA, int(shape.size)
+        for j in range(d.dim):
+            d.p0[j], d.p1[j], d.p2[j], d.p3[j] = float(shape[j]), float(rate[j]), float(scale[j]), float(gl[j])
+        return d
+
+    def gamma_descriptor(self):
+        """glabc_gamma (include/glabc.h), the float64 entry points glabc_gamma_log_prob / glabc_gamma_forward: float64 shape,
+        scale = 1/rate as distribution.py:133 forms it, gammaln(shape)"""
         from scipy.special import gammaln
         shape = np.asarray(self.Shape).reshape(-1)
         scale = np.asarray(1 / self.Rate).reshape(-1)
@@ -178,7 +197,7 @@ class Gamma(BaseDistribution):
 
     def log_prob(self, z, context=None):
         if z.is_cuda:
-            desc = self.descriptor()
+            desc = self.gamma_descriptor()
             zz = z.detach().to(torch.float64).reshape(z.shape[0], -1).contiguous()
             out = torch.empty(zz.shape[0], dtype=torch.float64, device=z.device)
             stream = torch.cuda.current_stream(z.device).cuda_stream

@@ -16,11 +16,14 @@ from ..distribution import _fill, _launch_rowwise, _launch_simulate
 
 
 class Mixture_set:
-    def __init__(self, epsilon):
+    def __init__(self, epsilon, prior=None):
         self.epsilon = epsilon
         self.theta_dim = 2
         self.y_obs = torch.tensor([[1.5, 1.5]])
         self.y_dim = self.y_obs.shape[1]
+        # an addition: another prior than the reference's N(0, I) (Mixture.py:30), any distribution.* object with a descriptor --
+        # e.g. distribution.Gamma, which the fused kernels evaluate in double (include/glabc.h GLABC_DIST_GAMMA)
+        self._prior_override = prior
 
     # the simulator's noise and the prior, as the reference constructs them per call
     def _likelihood(self):                      # Mixture.py:19
@@ -28,6 +31,8 @@ class Mixture_set:
                                          torch.log(torch.tensor([0.05, 0.05]).sqrt()))
 
     def _prior(self):                           # Mixture.py:30
+        if self._prior_override is not None:
+            return self._prior_override
         return distribution.DiagGaussian(self.theta_dim, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0]))
 
     def _kernel(self, epsilon):                 # Mixture.py:42-43

@@ -42,25 +42,37 @@ def try_descriptor(obj):
         return None
 
 
-def dist_descriptor(obj, dim):
-    """the object's glabc_dist if it has one that a sampler can draw from (DiagGaussian / Uniform of the right dimension)"""
+def dist_descriptor(obj, dim, gamma=False):
+    """the object's glabc_dist if it has one that a sampler can draw from (DiagGaussian / Uniform of the right dimension; a
+    Gamma only where the caller says the kernels know it -- `gamma`: the importance / global proposal of glabc_propose)"""
     d = try_descriptor(obj)
     if d is None or not isinstance(d, _capi.Dist):
-        return None                                          # e.g. Gamma (a glabc_gamma), GaussianMixture, a user's class
+        return None                                          # e.g. GaussianMixture, a user's class
+    if d.kind == _capi.DIST_GAMMA and not gamma:
+        return None                                          # a callback there: forward() / log_prob() on the device
     if d.dim != dim:
         raise ValueError("proposal dimension %d does not match Model.theta_dim = %d" % (d.dim, dim))
     return d
 
 
-def fused_supported(ABCset, proposals, batch_size, max_batch=None, max_dim=8):
-    """Can the fused kernels (glabc_glmcmc_steps / glabc_globalmcmc_steps / glabc_glmala_steps) run this configuration?"""
+def fused_supported(ABCset, proposals, batch_size, max_batch=None, max_dim=8, gamma_ok=False):
+    """Can the fused kernels (glabc_glmcmc_steps / glabc_globalmcmc_steps / glabc_glmala_steps) run this configuration?
+    gamma_ok: the entry point knows GLABC_DIST_GAMMA as the LAST proposal (importance / global) and as the Model's prior --
+    GLMCMC and GlobalMCMC on the |theta| + noise Model up to theta_dim 4 (include/glabc.h)."""
     m = try_descriptor(ABCset)
     if m is None or not isinstance(m, _capi.Model):
         return False
-    for p in proposals:
+    gamma = m.prior.kind == _capi.DIST_GAMMA
+    for i, p in enumerate(proposals):
         d = try_descriptor(p)
         if d is None or not isinstance(d, _capi.Dist) or d.dim != m.theta_dim:
             return False
+        if d.kind == _capi.DIST_GAMMA:
+            if i != len(proposals) - 1:
+                return False                                 # a Gamma local increment: callback
+            gamma = True
+    if gamma and not (gamma_ok and m.sim_kind == _capi.SIM_ABS_GAUSS and m.theta_dim <= 4):
+        return False
     if m.sim_kind == _capi.SIM_USER:                         # compiled.CompiledModel: register kernels only, compiled per batch size
         return hasattr(ABCset, "program") and (batch_size is None or 1 <= int(batch_size) <= _capi.MAX_BATCH)
     if m.sim_kind == _capi.SIM_ABS_GAUSS:                    # instantiated for theta_dim 1..8 (GLMALA and batch sizes > 16: 1..4)
@@ -174,7 +186,7 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     key = engine.draw_seed(seed)
     model = ModelCallbacks(ABCset, dev, callback_device)
     local_desc = dist_descriptor(Local_Proposal, d) if Local_Proposal is not None else None
-    global_desc = dist_descriptor(Global_Proposal, d)
+    global_desc = dist_descriptor(Global_Proposal, d, gamma=True)
     local_cb = ProposalCallbacks(Local_Proposal, dev) if (local_desc is None and Local_Proposal is not None) else None
     global_cb = ProposalCallbacks(Global_Proposal, dev) if global_desc is None else None
     if Local_Proposal is None and float(global_frequency) < 1:
@@ -713,7 +725,7 @@ def run_glmala(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad, fileloc
     model = ModelCallbacks(ABCset, dev, callback_device)
     if not hasattr(ABCset, "discrepancy"):
         raise TypeError("GLMALA needs Model.discrepancy (GLMALA.py:78)")
-    global_desc = dist_descriptor(Importance_Proposal, d)
+    global_desc = dist_descriptor(Importance_Proposal, d, gamma=True)
     global_cb = ProposalCallbacks(Importance_Proposal, dev) if global_desc is None else None
     tau = float(tau)
     eps_sq = float(ABCset.epsilon) ** 2                                                          # GLMALA.py:90

@@ -75,10 +75,23 @@ typedef struct glabc_dist {
     float p1[GLABC_MAX_DIM];       /* DiagGaussian log_scale  | Uniform high       | Gamma rate  */
     float p2[GLABC_MAX_DIM];       /* DiagGaussian exp(log_scale) exactly as the caller's exp returned it
                                       (distribution.py:170,178 recompute it per call; the round trip
-                                      exp(log(s)) != s matters for bit parity) | Uniform high-low | unused */
+                                      exp(log(s)) != s matters for bit parity) | Uniform high-low
+                                      | Gamma scale = 1/rate as the reference forms it (float32 division, distribution.py:118,133) */
+    float p3[GLABC_MAX_DIM];       /* Gamma scipy.special.gammaln(shape) (a float32 number: the reference keeps Shape as a float32
+                                      array, distribution.py:103) | unused otherwise */
     float c0;                      /* DiagGaussian f32(-0.5*dim*log(2*pi)) (distribution.py:171,177)
                                       | Uniform log_prob_val (distribution.py:71) | unused */
 } glabc_dist;
+
+/* GLABC_DIST_GAMMA inside the samplers (glabc_glmcmc_steps incl. batch sizes beyond GLABC_MAX_BATCH, glabc_globalmcmc_steps,
+ * glabc_propose / glabc_select, glabc_init_weights, glabc_dist_log_prob, the row-wise Model callbacks): accepted as the
+ * importance / global proposal and as the Model's prior (not as the local increment, not as simulator noise).  The reference's
+ * Gamma is float64 (distribution.py:106-137); the chains' state is float32 here, so
+ *   forward:  z_q = glabc_gamma_draw_candidate(shape_q; chain, iteration, candidate j, coordinate q) * scale_q in double
+ *             (include/glabc_numerics.h: Marsaglia-Tsang on the chain's Philox stream), theta'_q = (float) z_q,
+ *             log q' = (float) sum_q log(pdf(z_q))  -- the density of the double variate, summed in torch.sum's float64 order
+ *   log_prob: (float) sum_q log(pdf((double) theta_q)), -inf outside the support or where the pdf underflows (distribution.py:136)
+ * which is what the split-phase path does with a Gamma object's callbacks (results rounded to float32 for glabc_select). */
 
 /* ---- the Model callbacks: glabcmcmc/examples/Mixture.py:5-53 ------------- */
 typedef enum glabc_sim_kind {

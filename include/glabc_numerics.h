@@ -308,14 +308,16 @@ GLABC_HD double glabc_exp(double x)
  * -> the 53-bit accept uniform; attempt 0xffffffff feeds the shape < 1 boost.  Acceptance is > 75 % per attempt; after 256
  * rejected attempts (probability < 1e-150) the mode-like value d is returned so that every lane terminates.
  * Plain IEEE double operations: host and device agree bit for bit under -ffp-contract=off. */
-GLABC_HD double glabc_gamma_draw(double shape, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1)
+/* The general form: attempt t reads Philox(c0, c1, c2, slot0 + t), the shape < 1 boost Philox(c0, c1, c2, boost_slot). */
+GLABC_HD double glabc_gamma_draw_at(double shape, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t slot0, uint32_t boost_slot,
+                                    uint32_t k0, uint32_t k1)
 {
     const double a = shape < 1.0 ? shape + 1.0 : shape;
     const double d = a - 1.0 / 3.0;
     const double c = 1.0 / __builtin_sqrt(9.0 * d);
     double g = d;
     for (uint32_t t = 0; t < 256u; ++t) {
-        const glabc_u32x4 w = glabc_philox4x32_10(c0, c1, c2, t, k0, k1);
+        const glabc_u32x4 w = glabc_philox4x32_10(c0, c1, c2, slot0 + t, k0, k1);
         const double u1 = ((double)w.v[0] + 0.5) * 0x1p-31 - 1.0, u2 = ((double)w.v[1] + 0.5) * 0x1p-31 - 1.0;
         const double s = u1 * u1 + u2 * u2;
         if (!(s < 1.0) || s == 0.0) continue;
@@ -331,11 +333,44 @@ GLABC_HD double glabc_gamma_draw(double shape, uint32_t c0, uint32_t c1, uint32_
         }
     }
     if (shape < 1.0) {
-        const glabc_u32x4 w = glabc_philox4x32_10(c0, c1, c2, 0xffffffffu, k0, k1);
+        const glabc_u32x4 w = glabc_philox4x32_10(c0, c1, c2, boost_slot, k0, k1);
         const double u = (((double)(w.v[0] >> 5) * 67108864.0 + (double)(w.v[1] >> 6)) + 0.5) * 0x1p-53;       /* in (0, 1) */
         g = g * glabc_exp(glabc_log(u) / shape);
     }
     return g;
+}
+
+/* glabc_gamma_forward (include/glabc.h): counter (row id lo, hi, coordinate, attempt), boost in attempt 0xffffffff */
+GLABC_HD double glabc_gamma_draw(double shape, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1)
+{
+    return glabc_gamma_draw_at(shape, c0, c1, c2, 0u, 0xffffffffu, k0, k1);
+}
+
+/* Gamma as the importance / global proposal INSIDE a sampler iteration (glabc_dist kind GLABC_DIST_GAMMA): coordinate q of
+ * candidate j of (chain, iteration) draws from counter (chain id lo, hi, iteration, GLABC_SLOT_GAMMA + ((j*8 + q) << 9) + attempt),
+ * attempt < 256, the shape < 1 boost from attempt 256 -- a region of the slot word that neither the candidates' own blocks
+ * (1 + j*spp + b < 2^15), GLMALA's gradient noise (< 2^22) nor the local move's redraws (GLABC_SLOT_REDRAW = 2^30) reach. */
+#define GLABC_SLOT_GAMMA 0x20000000u
+GLABC_HD double glabc_gamma_draw_candidate(double shape, uint32_t c0, uint32_t c1, uint32_t step, int j, int q, uint32_t k0,
+                                           uint32_t k1)
+{
+    const uint32_t slot0 = GLABC_SLOT_GAMMA + (((uint32_t)j * 8u + (uint32_t)q) << 9);
+    return glabc_gamma_draw_at(shape, c0, c1, step, slot0, slot0 + 256u, k0, k1);
+}
+
+/* one coordinate of Gamma.log_prob, distribution.py:133-136, float64: log(scipy.stats.gamma.pdf(z, shape, scale = 1/rate)) with
+ * -inf where the pdf is 0 (it underflows earlier than a logpdf would -- reproduced);
+ *   pdf = exp(xlogy(shape - 1, x) - x - gammaln(shape)) / scale,  x = z / scale,  0 for x < 0 */
+GLABC_HD double glabc_gamma_log_pdf(double shape, double scale, double gammaln, double z)
+{
+    const double x = z / scale;
+    if (x >= 0.0) {                                        /* scipy's support of gamma is closed at 0 */
+        const double am1 = shape - 1.0;
+        const double xl = am1 == 0.0 ? 0.0 : am1 * glabc_log(x);                       /* scipy.special.xlogy */
+        const double p = glabc_exp((xl - x) - gammaln) / scale;                        /* gamma.pdf */
+        return p > 0.0 ? glabc_log(p) : -__builtin_inf();                              /* distribution.py:136 */
+    }
+    return -__builtin_inf();
 }
 
 /* ---- exact, order-independent sums for GLMALA's gradient statistics (GLMALA.py:86-89) ------------------------

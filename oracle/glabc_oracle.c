@@ -158,11 +158,59 @@ static float uniform_forward(const glabc_dist* g, const float* u, float* z)
     return g->c0;
 }
 
+static double aten_rowsum_f64(const double* x, int n);
+
+/* Gamma.log_prob, distribution.py:123-137, at a float32 point (include/glabc.h, GLABC_DIST_GAMMA inside the samplers): float64 per
+ * coordinate -- log(scipy.stats.gamma.pdf), -inf where the pdf is 0 -- summed as torch.sum sums a float64 row, rounded once */
+static float gamma_dist_log_prob(const glabc_dist* g, const float* z)
+{
+    double t[GLABC_MAX_DIM];
+    for (int j = 0; j < g->dim; ++j) t[j] = glabc_gamma_log_pdf((double)g->p0[j], (double)g->p2[j], (double)g->p3[j], (double)z[j]);
+    return (float)aten_rowsum_f64(t, g->dim);
+}
+
+/* Gamma.forward, distribution.py:106-121, for candidate j of (chain, step): the double variates from the chain's Gamma slots
+ * (glabc_gamma_draw_candidate), theta' = (float) z, log_p = (float) log_prob of the DOUBLE variate (:120) */
+static float gamma_dist_forward(const glabc_dist* g, uint64_t seed, uint64_t chain, uint32_t step, int j, float* z)
+{
+    double t[GLABC_MAX_DIM];
+    for (int q = 0; q < g->dim; ++q) {
+        const double v = glabc_gamma_draw_candidate((double)g->p0[q], (uint32_t)chain, (uint32_t)(chain >> 32), step, j, q,
+                                                    (uint32_t)seed, (uint32_t)(seed >> 32)) * (double)g->p2[q];   /* gamma.rvs(shape, scale=1/rate) */
+        z[q] = (float)v;
+        t[q] = glabc_gamma_log_pdf((double)g->p0[q], (double)g->p2[q], (double)g->p3[q], v);
+    }
+    return (float)aten_rowsum_f64(t, g->dim);
+}
+
+/* test hook: the DOUBLE variates and log-densities behind gamma_dist_forward for candidates 0 .. n_prop-1 of (chain, step) --
+ * what the reference's Gamma.forward returns when its scipy draw is replaced by these variates (tests/golden/make_golden.py
+ * gamma_candidates_fixture).  z[n_prop][dim], log_p[n_prop]. */
+ORACLE_API int oracle_gamma_candidates(const glabc_dist* g, uint64_t seed, uint64_t chain, uint32_t step, int n_prop, double* z,
+                                       double* log_p)
+{
+    if (!g || !z || !log_p) return GLABC_ERR_NULL;
+    if (g->kind != GLABC_DIST_GAMMA) return GLABC_ERR_KIND;
+    if (g->dim < 1 || g->dim > GLABC_MAX_DIM) return GLABC_ERR_DIM;
+    for (int j = 0; j < n_prop; ++j) {
+        double t[GLABC_MAX_DIM];
+        for (int q = 0; q < g->dim; ++q) {
+            const double v = glabc_gamma_draw_candidate((double)g->p0[q], (uint32_t)chain, (uint32_t)(chain >> 32), step, j, q,
+                                                        (uint32_t)seed, (uint32_t)(seed >> 32)) * (double)g->p2[q];
+            z[j * g->dim + q] = v;
+            t[q] = glabc_gamma_log_pdf((double)g->p0[q], (double)g->p2[q], (double)g->p3[q], v);
+        }
+        log_p[j] = aten_rowsum_f64(t, g->dim);
+    }
+    return 0;
+}
+
 static int dist_log_prob(const glabc_dist* g, const float* z, float* out)
 {
     switch (g->kind) {
     case GLABC_DIST_DIAG_GAUSS: *out = diag_gauss_log_prob(g, z); return 0;
     case GLABC_DIST_UNIFORM: *out = uniform_log_prob(g, z); return 0;
+    case GLABC_DIST_GAMMA: *out = gamma_dist_log_prob(g, z); return 0;
     default: return GLABC_ERR_KIND;
     }
 }
@@ -396,6 +444,9 @@ typedef struct step_draws {
     float u_branch;                                 /* torch.rand(1)            GLMCMC.py:59 */
     float u_accept;                                 /* torch.rand(1)            GLMCMC.py:98 */
     double u_resample;                              /* np.random.uniform(0,1)   GLMCMC.py:17 */
+    uint64_t seed, chain;                           /* the (chain, step) the draws belong to: a Gamma proposal draws its */
+    uint32_t step;                                  /* variates from the chain's own Gamma slots (gamma_dist_forward)     */
+    int philox;                                     /* 0: replayed from a tape (no Gamma variates there) */
     float (*z)[2 * GLABC_MAX_DIM];                  /* per proposal: d proposal draws then y_dim simulator draws */
     float zs[GLABC_MAX_BATCH][2 * GLABC_MAX_DIM];   /* storage for up to GLABC_MAX_BATCH proposals; larger batches: heap */
 } step_draws;
@@ -428,6 +479,10 @@ static void draws_from_philox(step_draws* s, uint64_t seed, uint64_t chain, uint
 {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     uint32_t c0 = (uint32_t)chain, c1 = (uint32_t)(chain >> 32);
+    s->seed = seed;
+    s->chain = chain;
+    s->step = step;
+    s->philox = 1;
     glabc_u32x4 h = glabc_philox4x32_10(c0, c1, step, 0u, k0, k1);
     s->u_branch = glabc_uniform_f32(h.v[0]);
     s->u_accept = glabc_uniform_f32(h.v[1]);
@@ -455,6 +510,7 @@ static void draws_from_tape(step_draws* s, const glabc_tape* t, int64_t chain_lo
                             int n_prop, int d, int yd)
 {
     int64_t ct = chain_local * n_steps + t_idx;
+    s->philox = 0;
     s->u_branch = t->u[2 * ct + 0];
     s->u_accept = t->u[2 * ct + 1];
     s->u_resample = t->r ? t->r[ct] : 0.0;
@@ -471,6 +527,17 @@ static int prop_forward(const glabc_dist* g, const float* noise, float* z, float
     if (g->kind == GLABC_DIST_DIAG_GAUSS) { *log_p = diag_gauss_forward(g, noise, z); return 0; }
     if (g->kind == GLABC_DIST_UNIFORM) { *log_p = uniform_forward(g, noise, z); return 0; }
     return GLABC_ERR_KIND;
+}
+
+/* candidate j of the iteration the draws belong to: a Gamma importance / global proposal ignores the noise row */
+static int prop_forward_j(const glabc_dist* g, const step_draws* dr, int j, float* z, float* log_p)
+{
+    if (g->kind == GLABC_DIST_GAMMA) {
+        if (!dr->philox) return GLABC_ERR_ARG;
+        *log_p = gamma_dist_forward(g, dr->seed, dr->chain, dr->step, j, z);
+        return 0;
+    }
+    return prop_forward(g, dr->z[j], z, log_p);
 }
 
 typedef struct chain_state {
@@ -589,7 +656,7 @@ static int isir_move(const glabc_model* m, const glabc_dist* imp, int N, chain_s
     int n = 1;
     for (int j = 0; j < N; ++j) {
         float lq;
-        prop_forward(imp, dr->z[j], th[n], &lq);                                    /* :66 */
+        prop_forward_j(imp, dr, j, th[n], &lq);                                     /* :66 */
         int has_nan = 0;
         for (int k = 0; k < d; ++k) has_nan |= isnan(th[n][k]);
         if (has_nan) continue;                                                      /* :67-70 */
@@ -690,7 +757,7 @@ static int independence_move(const glabc_model* m, const glabc_dist* glob, chain
 {
     int d = m->theta_dim, yd = m->y_dim;
     float th[GLABC_MAX_DIM], y[GLABC_MAX_DIM], lq_new, lq_old = 0.0f;
-    prop_forward(glob, dr->z[0], th, &lq_new);
+    prop_forward_j(glob, dr, 0, th, &lq_new);
     model_simulate(m, th, dr->z[0] + d, y);
     dist_log_prob(glob, s->theta, &lq_old);
     float log_acc = ((((model_prior(m, th) + model_log_kernel(m, y)) + lq_old) - lq_new) - model_prior(m, s->theta)) -
@@ -1826,7 +1893,12 @@ ORACLE_API int oracle_propose(int algo, const glabc_dist* local, const glabc_dis
             candidate_draws(run->seed, chain, step, j, d, nd, g && g->kind == GLABC_DIST_UNIFORM, e,
                             io->sim_noise ? io->sim_noise + r * nd : NULL);
             if (!g) continue;                                                   /* the caller fills these rows */
-            rc = prop_forward(g, e, z, &lq);                                    /* GLMCMC.py:66 / :91 */
+            if (g->kind == GLABC_DIST_GAMMA && !(j == 0 && !is_global)) {       /* a Gamma importance / global proposal */
+                lq = gamma_dist_forward(g, run->seed, chain, step, j, z);
+                rc = 0;
+            } else {
+                rc = prop_forward(g, e, z, &lq);                                /* GLMCMC.py:66 / :91 */
+            }
             if (rc) return rc;
             if (j == 0 && !is_global) {
                 for (int k = 0; k < d; ++k) z[k] = z[k] + c->theta[k * c->stride + i];    /* GLMCMC.py:91 */

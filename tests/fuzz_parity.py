@@ -51,6 +51,13 @@ def one_case(rng, oracle, k):
         ("gauss", [float(v) for v in rng.normal(0, 0.3, d)], [float(v) for v in np.exp(rng.normal(0.2, 0.4, d))])
     if rng.random() < 0.15:
         pspec = ("uniform", [-4.0] * d, [4.0] * d)
+    if d <= 4 and rng.random() < 0.12:                # GLABC_DIST_GAMMA as importance / global proposal and / or prior (VAR_GAMMA)
+        gam = lambda: ("gamma", [float(v) for v in np.exp(rng.normal(0.7, 0.8, d))], [float(v) for v in np.exp(rng.normal(0.5, 0.5, d))])  # noqa: E731
+        which = int(rng.integers(0, 3))
+        if which != 1:
+            gspec = gam()
+        if which != 0:
+            pspec = gam()
     model.prior = make_dist(pspec).descriptor()
     model.noise = make_dist(("gauss", [0.0] * d, [float(v) for v in np.exp(rng.normal(-1.5, 0.3, d))])).descriptor()
     y_obs = [float(v) for v in rng.choice([0.0, 1e-3, 1.5, float(rng.normal(1, 1))], d)]
@@ -73,8 +80,15 @@ def one_case(rng, oracle, k):
     hist = torch.empty(T, d, n, device=dev)
     mom = engine.Moments(n, d, dev)
     entry = "glabc_glmcmc_steps" if algo == "glmcmc" else "glabc_globalmcmc_steps"
+    # launch geometry: one in four GLMCMC cases forces the team kernels (glabc_team.h: 2 .. 4 wavefronts per 64 chains; the
+    # library falls back to fewer wavefronts, or to sampler_kernel, where the configuration has no such team)
+    team = 0
+    if algo == "glmcmc" and not wide and rng.random() < 0.25:
+        team = int(rng.integers(2, 5))
+        os.environ["GLABC_TEAM_WAVES"] = str(team)
     engine.run_steps(entry, model, local, glob, chains, T, 1, seed, gf, N, history=hist, moments=mom, steps_per_launch=spl,
-                     lanes_per_chain=lanes)
+                     lanes_per_chain=0 if team else lanes, debug_flags=_capi.DEBUG_TEAM if team else 0)
+    os.environ.pop("GLABC_TEAM_WAVES", None)
     torch.cuda.synchronize()
     hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
     hh = np.zeros((T, d, n), np.float32)
@@ -88,7 +102,7 @@ def one_case(rng, oracle, k):
         rc = oracle.oracle_globalmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run))
     assert rc == 0
     desc = dict(case=k, algo=algo, d=d, N=N, eps=eps, gf=gf, local=lspec, glob=gspec, prior=pspec, y_obs=y_obs,
-                n=n, T=T, lanes=lanes, spl=spl)
+                n=n, T=T, lanes=lanes, spl=spl, team=team)
     ok = np.array_equal(bits(hist.cpu().numpy()), bits(hh)) and np.array_equal(bits(chains.theta.cpu().numpy()), bits(hc.theta)) \
         and np.array_equal(bits(chains.y.cpu().numpy()), bits(hc.y)) and np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
     if algo == "glmcmc":

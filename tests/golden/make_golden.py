@@ -513,7 +513,7 @@ def primitives():
     for tag, shape, rate, seed, row0 in (("a", [2.0, 3.0], [1.0, 2.0], 11, 0), ("b", [0.5], [3.0], 12, 10 ** 12),
                                          ("c", [1.0, 7.5, 0.3], [0.5, 1.5, 4.0], 13, 77)):
         g = rdist.Gamma(torch.tensor(shape), torch.tensor(rate))
-        desc = bdist.Gamma(torch.tensor(shape), torch.tensor(rate)).descriptor()
+        desc = bdist.Gamma(torch.tensor(shape), torch.tensor(rate)).gamma_descriptor()
         n, k = 400, len(shape)
         zz, lp = np.empty((n, k)), np.empty(n)
         assert L.oracle_gamma_forward(ctypes.byref(desc), n, seed, row0, zz.ctypes.data, lp.ctypes.data) == 0
@@ -744,8 +744,53 @@ def kde_fixture():
     print("kde: %d arrays" % len(out))
 
 
+def gamma_candidates_fixture():
+    """Gamma as the importance proposal INSIDE the samplers (include/glabc.h GLABC_DIST_GAMMA): the variates come from the
+    chain's Gamma slots (include/glabc_numerics.h glabc_gamma_draw_candidate, through the CPU checker's test hook); the
+    reference's own Gamma.forward (distribution.py:106-121), with scipy's draw replaced by exactly those variates, returns
+    (z, log_prob(z)) -- stored, so that the checker's (and the kernels') log q' is pinned to the reference's float64
+    log(pdf) sum.  Also Gamma.log_prob (distribution.py:123-137) at float32 points, as a prior is evaluated."""
+    import ctypes
+    import scipy.stats
+    from glabcmcmc_amd import distribution as bdist
+    L = oracle_lib.load()
+    L.oracle_gamma_candidates.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(424242)
+    out, cases = {}, []
+    for i, (shape, rate, seed, chain, step, N) in enumerate((
+            ([4.0, 4.0], [3.0, 3.0], 5, 0, 1, 64), ([0.5, 2.5], [1.0, 0.25], 77, 10 ** 12 + 3, 4000000000, 40),
+            ([1.0], [2.0], 9, 123456, 17, 100), ([7.5, 0.3, 1.0, 2.0], [1.5, 4.0, 0.5, 1.0], 2026, 65535, 2000, 33),
+            ([3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0], [1.0, 2.0, 3.0, 4.0, 0.5, 0.25, 8.0, 1.5], 1, 1, 1, 12))):
+        k = len(shape)
+        g = rdist.Gamma(torch.tensor(shape), torch.tensor(rate))
+        desc = bdist.Gamma(torch.tensor(shape), torch.tensor(rate)).descriptor()
+        zz, lp = np.empty((N, k)), np.empty(N)
+        assert L.oracle_gamma_candidates(ctypes.byref(desc), seed, chain, step, N, zz.ctypes.data, lp.ctypes.data) == 0
+        saved = scipy.stats.gamma.rvs
+        rdist.gamma.rvs = lambda a, scale=1, size=None, zz=zz: zz.copy()
+        try:
+            z_ref, lp_ref = g.forward(N)
+        finally:
+            rdist.gamma.rvs = saved
+        assert np.array_equal(z_ref.numpy(), zz)
+        # log_prob at float32 points (a prior's use): positive, zero, negative, far in the tail (pdf underflows -> -inf)
+        pts = np.abs(rng.standard_normal((200, k))).astype(np.float32) * np.float32(2.0)
+        pts[0, 0], pts[1, 0], pts[2, 0], pts[3, 0] = 0.0, -0.5, 3000.0, 1e-30
+        lp_pts = g.log_prob(torch.from_numpy(pts).double()).numpy()
+        out["gc_%d_shape" % i], out["gc_%d_rate" % i] = np.array(shape, np.float32), np.array(rate, np.float32)
+        out["gc_%d_z" % i], out["gc_%d_log_p" % i] = z_ref.numpy(), lp_ref.numpy()
+        out["gc_%d_pts" % i], out["gc_%d_pts_log_prob" % i] = pts, lp_pts
+        cases.append((i, seed, chain, step, N))
+    out["cases"] = np.array(repr(cases))
+    np.savez_compressed(os.path.join(HERE, "gamma_candidates.npz"), **out)
+    print("gamma_candidates: %d arrays" % len(out))
+
+
 if __name__ == "__main__":
     want = sys.argv[1:]
+    if not want or "gamma_candidates" in want:
+        gamma_candidates_fixture()
     if not want or "kde" in want:
         kde_fixture()
     if not want or "aglmcmc" in want:

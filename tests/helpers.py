@@ -19,8 +19,10 @@ def load_golden(name):
 
 
 def make_dist(spec):
-    """('gauss', loc, scale) / ('uniform', low, high) -> host-mirror distribution object"""
+    """('gauss', loc, scale) / ('uniform', low, high) / ('gamma', shape, rate) -> host-mirror distribution object"""
     kind = spec[0]
+    if kind == "gamma":
+        return distribution.Gamma(torch.tensor(spec[1], dtype=torch.float32), torch.tensor(spec[2], dtype=torch.float32))
     if kind == "gauss":
         return distribution.DiagGaussian(len(spec[1]), torch.tensor(spec[1], dtype=torch.float32),
                                          torch.log(torch.tensor(spec[2], dtype=torch.float32)))

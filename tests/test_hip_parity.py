@@ -640,7 +640,7 @@ def test_gamma_log_prob_on_gpu(hip, oracle, prim):
     from glabcmcmc_amd import distribution
     for tag in ("a", "b", "c"):
         g = distribution.Gamma(torch.from_numpy(prim["gm_%s_shape" % tag]), torch.from_numpy(prim["gm_%s_rate" % tag]))
-        d = g.descriptor()
+        d = g.gamma_descriptor()
         z = prim["gm_%s_z" % tag]
         o = np.empty(len(z))
         assert oracle.oracle_gamma_log_prob(C.byref(d), z.ctypes.data, len(z), o.ctypes.data) == 0
@@ -1015,7 +1015,7 @@ def test_gamma_forward_on_gpu(hip, oracle):
         seed, row0 = (int(v) for v in prim["gf_%s_seed_row0" % tag])
         n = 100000
         z, lp = g.forward(n, seed=seed, row0=row0)
-        d = g.descriptor()
+        d = g.gamma_descriptor()
         zo, lo = np.empty((n, d.dim)), np.empty(n)
         assert oracle.oracle_gamma_forward(C.byref(d), n, seed, row0, zo.ctypes.data, lo.ctypes.data) == 0
         assert z.dtype == torch.float64 and np.array_equal(z.cpu().numpy().reshape(n, -1).view(np.uint64), zo.view(np.uint64)), tag
@@ -1050,3 +1050,118 @@ def test_gamma_importance_proposal_runs_glmcmc(hip):
     se = per_chain.std(ddof=1) / np.sqrt(n)
     assert abs(per_chain.mean() - want_sq) < 5 * se + 3e-3 * want_sq, (per_chain.mean(), want_sq, se)
     assert (ch.theta > 0).float().mean() > 0.95          # iSIR moves land on the Gamma's support; local moves rarely cross 0
+
+
+# ---------------------------------------------------------------------------------- Gamma inside the samplers (a9)
+def _gamma_desc(shape, rate):
+    from glabcmcmc_amd import distribution
+    return distribution.Gamma(torch.tensor(shape, dtype=torch.float32), torch.tensor(rate, dtype=torch.float32)).descriptor()
+
+
+GAMMA_CASES = [
+    # algo, d, N, gf, importance / global, prior, chains, T
+    ("glmcmc", 2, 5, 0.8, ("gamma", [4.0, 4.0], [3.0, 3.0]), None, 700, 150),
+    ("glmcmc", 2, 5, 0.8, ("gauss", [0.8, 0.8], [1.0, 1.0]), ("gamma", [2.0, 3.0], [1.5, 2.0]), 513, 150),
+    ("glmcmc", 2, 3, 0.6, ("gamma", [0.5, 2.5], [1.0, 1.5]), ("gamma", [2.0, 2.0], [1.0, 1.0]), 300, 120),       # shape < 1: the boost draw
+    ("glmcmc", 1, 16, 0.9, ("gamma", [3.0], [2.0]), None, 200, 80),
+    ("glmcmc", 4, 4, 0.7, ("gamma", [4.0, 4.0, 4.0, 4.0], [3.0, 3.0, 3.0, 3.0]), ("gamma", [2.0] * 4, [1.0] * 4), 130, 80),
+    ("glmcmc", 2, 40, 0.8, ("gamma", [4.0, 4.0], [3.0, 3.0]), ("gamma", [2.0, 3.0], [1.5, 2.0]), 200, 60),         # wide kernel
+    ("glmcmc", 3, 100, 1.0, ("gamma", [4.0, 2.0, 1.0], [3.0, 1.0, 1.0]), None, 70, 40),                            # wide, 16 lanes
+    ("globalmcmc", 2, 1, 0.5, ("gamma", [4.0, 4.0], [3.0, 3.0]), ("gamma", [2.0, 3.0], [1.5, 2.0]), 640, 200),
+]
+
+
+@pytest.mark.parametrize("case", GAMMA_CASES, ids=lambda c: "%s-d%d-N%d-%s-%s" % (c[0], c[1], c[2], c[4][0], c[5][0] if c[5] else "gaussprior"))
+def test_gamma_inside_the_fused_kernels(hip, oracle, case):
+    """GLABC_DIST_GAMMA as importance / global proposal and as prior in sampler_kernel (VAR_GAMMA), wide_kernel and
+    init_weights (include/glabc.h; distribution.py:90-137): histories, states, weights, counters and sums equal the CPU
+    checker's bit for bit; the chains live on the Gamma's support."""
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import distribution
+    algo, d, N, gf, gspec, pspec, n, T = case
+    model, local, glob = descriptors(dict(epsilon=0.3, local=("gauss", [0] * 2, [0.3] * 2), **{"global": ("gauss", [0] * 2, [1] * 2)}))
+    noise = distribution.DiagGaussian(d, torch.zeros(d), torch.log(torch.full((d,), 0.05).sqrt())).descriptor()
+    model.theta_dim = model.y_dim = d
+    model.noise = noise
+    for j in range(d):
+        model.y_obs[j] = 1.5 - 0.25 * j
+    model.prior = _gamma_desc(*pspec[1:]) if pspec else distribution.DiagGaussian(d, torch.zeros(d), torch.zeros(d)).descriptor()
+    local = make_dist(("gauss", [0.0] * d, [0.3] * d)).descriptor()
+    glob = _gamma_desc(*gspec[1:]) if gspec[0] == "gamma" else make_dist((gspec[0], gspec[1][:d], gspec[2][:d])).descriptor()
+    rng = np.random.default_rng(17 * N + d)
+    theta0 = (np.abs(rng.standard_normal((n, d))) + 0.2).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    hist, chains, mom = hip_run(algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True,
+                                steps_per_launch=33)
+    hh, hc, hm = oracle_run(oracle, algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True)
+    same = bits(hist) == bits(hh)
+    assert same.all(), "first mismatch at (t, dim, chain) = %s" % (np.argwhere(~same)[0],)
+    assert_same_state(chains, hc, algo == "glmcmc")
+    assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
+    assert hc.n_moves.sum() > n // 4
+    if pspec:
+        assert (hist[T // 2:] >= 0).all()                   # a Gamma prior: no state outside its support survives
+
+
+def test_gamma_split_phase_equals_fused(hip):
+    """The same iteration cut at the Model's callbacks: glabc_propose draws the Gamma candidates from the same slots, the
+    Model's prior_log_prob is the Gamma prior through the row-wise kernel, glabc_select decides -- the chains equal the fused
+    kernel's bit for bit (GLMCMC and GlobalMCMC), through the package's own functions."""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import distribution, engine
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    prior = distribution.Gamma(torch.tensor([2.0, 3.0]), torch.tensor([1.5, 2.0]))
+    m = Mixture_set(0.3, prior=prior)
+    lp = distribution.DiagGaussian(2, torch.zeros(1, 2), torch.log(torch.tensor([0.3, 0.3])))
+    ip = distribution.Gamma(torch.tensor([4.0, 4.0]), torch.tensor([3.0, 3.0]))
+    n, T = 1500, 60
+    gen = torch.Generator().manual_seed(3)
+    th0 = torch.randn(n, 2, generator=gen).abs() + 0.2
+    y0 = th0 + 0.2236 * torch.randn(n, 2, generator=gen)
+    dev = torch.device("cuda", 0)
+    for fn, args in ((g_.GLMCMC, (lp, None, 0.8, ip, 5)), (g_.GlobalMCMC, (ip, None, 0.5, lp))):
+        outs = []
+        for path in ("fused", "generic"):
+            mom = engine.Moments(n, 2, dev)
+            h = fn(m, T + 1, th0, y0, *args, seed=11, stats=mom, return_device=True, verbose=False, path=path)
+            outs.append((h.cpu().numpy(), mom.sum_jump.cpu().numpy()))
+        assert np.array_equal(bits(outs[0][0]), bits(outs[1][0])), fn.__name__
+        assert np.array_equal(outs[0][1].view(np.uint64), outs[1][1].view(np.uint64))
+        assert (np.diff(outs[0][0], axis=0) != 0).any(-1).mean() > 0.02
+    # `auto` picks the fused kernels for this configuration, and refuses nothing
+    from glabcmcmc_amd import generic
+    assert generic.fused_supported(m, (lp, ip), 5, gamma_ok=True) and not generic.fused_supported(m, (lp, ip), 5)
+    assert not generic.fused_supported(m, (ip, ip), 5, gamma_ok=True)          # a Gamma local increment is a callback
+
+
+def test_gamma_descriptor_entry_points(hip, oracle):
+    """glabc_dist_log_prob / the row-wise prior with a Gamma descriptor == the CPU checker bit for bit (the reference-pinned
+    values: tests/test_oracle_golden.py); what the ABI refuses: a Gamma local increment, Gamma in GLMALA and the pool kernels"""
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import engine
+    g = load_golden("gamma_candidates")
+    dev = torch.device("cuda", 0)
+    for i in range(5):
+        d = _gamma_desc(g["gc_%d_shape" % i].tolist(), g["gc_%d_rate" % i].tolist())
+        pts = g["gc_%d_pts" % i]
+        want = np.empty(len(pts), np.float32)
+        assert oracle.oracle_dist_log_prob(C.byref(d), pts.ctypes.data, len(pts), want.ctypes.data) == 0
+        z = torch.from_numpy(pts).to(dev)
+        out = torch.empty(len(pts), dtype=torch.float32, device=dev)
+        assert hip.glabc_dist_log_prob(C.byref(d), z.data_ptr(), len(pts), out.data_ptr(), None) == 0
+        assert np.array_equal(bits(out.cpu().numpy()), bits(want)), i
+    model, local, glob = descriptors(dict(epsilon=0.3, local=("gauss", [0, 0], [0.3, 0.3]), **{"global": ("gauss", [0, 0], [1, 1])}))
+    gam = _gamma_desc([2.0, 2.0], [1.0, 1.0])
+    chains = engine.ChainBatch(torch.ones(8, 2), torch.ones(8, 2), dev).add_mala_state()
+    cs = chains.struct()
+    run = A.Run()
+    run.seed, run.step0, run.n_steps, run.global_frequency, run.batch_size = 1, 1, 2, 0.5, 5
+    assert hip.glabc_glmcmc_steps(C.byref(model), C.byref(gam), C.byref(glob), C.byref(cs), C.byref(run), None) == -3      # local
+    assert hip.glabc_glmcmc_steps(C.byref(model), C.byref(local), C.byref(gam), C.byref(cs), C.byref(run), None) == 0
+    mala = A.Mala(0.3, 0.09, 0.09, 10, 0)
+    assert hip.glabc_glmala_steps(C.byref(model), C.byref(gam), C.byref(mala), C.byref(cs), C.byref(run), None) == -3
+    bad = _gamma_desc([2.0, 2.0], [1.0, 1.0])
+    bad.p0[1] = -1.0
+    assert hip.glabc_glmcmc_steps(C.byref(model), C.byref(local), C.byref(bad), C.byref(cs), C.byref(run), None) == -4
+    torch.cuda.synchronize()

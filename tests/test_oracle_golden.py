@@ -258,7 +258,7 @@ def test_gamma_log_prob(oracle, prim, tag):
     import torch
     from glabcmcmc_amd import distribution
     g = distribution.Gamma(torch.from_numpy(prim["gm_%s_shape" % tag]), torch.from_numpy(prim["gm_%s_rate" % tag]))
-    d = g.descriptor()
+    d = g.gamma_descriptor()
     z, ref = prim["gm_%s_z" % tag], prim["gm_%s_log_prob" % tag]
     out = np.empty(len(z))
     assert oracle.oracle_gamma_log_prob(C.byref(d), z.ctypes.data, len(z), out.ctypes.data) == 0
@@ -279,7 +279,7 @@ def test_gamma_forward(oracle, prim, tag):
     import torch
     from glabcmcmc_amd import distribution
     g = distribution.Gamma(torch.from_numpy(prim["gf_%s_shape" % tag]), torch.from_numpy(prim["gf_%s_rate" % tag]))
-    d = g.descriptor()
+    d = g.gamma_descriptor()
     seed, row0 = (int(v) for v in prim["gf_%s_seed_row0" % tag])
     z_ref, lp_ref = prim["gf_%s_z" % tag], prim["gf_%s_log_p" % tag]
     z, lp = np.empty_like(z_ref), np.empty_like(lp_ref)
@@ -317,3 +317,65 @@ def test_aten_restatement_replays_the_reference_tapes(name):
         else:
             out = aten_loop.globalmcmc(model, T, th0, y0, glob, local, cfg["gf"], draws)
         assert np.array_equal(bits(out.numpy()), bits(g["chains"][:, c, :])), "chain %d" % c
+
+
+# ---------------------------------------------------------------------------------- Gamma inside the samplers
+def _gamma_cases():
+    import ast
+    g = load_golden("gamma_candidates")
+    return g, ast.literal_eval(str(g["cases"]))
+
+
+def test_gamma_candidates_match_the_reference_forward(oracle):
+    """GLABC_DIST_GAMMA as the importance proposal (include/glabc.h): the checker's double variates are the ones the fixture
+    fed to the reference's Gamma.forward (distribution.py:106-121), and its float64 log q' is the reference's log_prob of
+    them to 1e-12 (scipy's log / exp / gammaln against the specified ones); through oracle_propose the candidates are those
+    variates rounded to float32 once."""
+    import torch
+    from glabcmcmc_amd import _capi as A, distribution
+    g, cases = _gamma_cases()
+    oracle.oracle_gamma_candidates.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    for i, seed, chain, step, N in cases:
+        shape, rate = g["gc_%d_shape" % i], g["gc_%d_rate" % i]
+        d = distribution.Gamma(torch.from_numpy(shape), torch.from_numpy(rate)).descriptor()
+        assert d.kind == A.DIST_GAMMA and d.dim == len(shape)
+        k = d.dim
+        z, lp = np.empty((N, k)), np.empty(N)
+        assert oracle.oracle_gamma_candidates(C.byref(d), seed, chain, step, N, z.ctypes.data, lp.ctypes.data) == 0
+        assert np.array_equal(z.view(np.uint64), g["gc_%d_z" % i].view(np.uint64)), i
+        ref = g["gc_%d_log_p" % i]
+        assert np.all(np.abs(lp - ref) <= 1e-12 * np.maximum(1.0, np.abs(ref))), (i, np.abs(lp - ref).max())
+        assert (z > 0).all() and np.isfinite(lp).all()
+        mean = z.mean(0)
+        want = shape.astype(np.float64) / rate
+        assert np.all(np.abs(mean - want) < 0.6 * want), (mean, want)               # the right distribution (few draws)
+        # the split-phase draw: theta' = (float) z, log q' = (float) log_p
+        hc = oracle_lib.HostChains(np.zeros((1, k), np.float32), np.zeros((1, k), np.float32), chain0=chain)
+        cs = hc.struct()
+        h = dict(theta_prop=np.zeros((N, k), np.float32), log_q=np.zeros(N, np.float32), log_u=np.zeros(1, np.float32),
+                 u_res=np.zeros(1, np.float64), is_global=np.zeros(1, np.int32))
+        io = A.StepIO(N, k, k, 0, h["theta_prop"].ctypes.data, h["log_q"].ctypes.data, None, h["log_u"].ctypes.data,
+                      h["u_res"].ctypes.data, h["is_global"].ctypes.data, None, None, None, None, None, None)
+        run, keep = oracle_lib.make_run(seed=seed, step0=step, n_steps=1, gf=1.0, batch=N)
+        assert oracle.oracle_propose(A.ALGO_GLMCMC, None, C.byref(d), C.byref(cs), C.byref(run), C.byref(io)) == 0
+        assert np.array_equal(bits(h["theta_prop"]), bits(z.astype(np.float32)))
+        assert np.array_equal(bits(h["log_q"]), bits(lp.astype(np.float32)))
+
+
+def test_gamma_log_prob_at_float32_points_matches_the_reference(oracle):
+    """Gamma.log_prob (distribution.py:123-137) as a prior is evaluated: float64 at the float32 point, -inf outside the support
+    and where the pdf underflows (B7), rounded to float32 once -- within one float32 ulp of the reference's float64 sum."""
+    import torch
+    from glabcmcmc_amd import distribution
+    g, cases = _gamma_cases()
+    for i, *_ in cases:
+        d = distribution.Gamma(torch.from_numpy(g["gc_%d_shape" % i]), torch.from_numpy(g["gc_%d_rate" % i])).descriptor()
+        pts, ref = g["gc_%d_pts" % i], g["gc_%d_pts_log_prob" % i]
+        out = np.empty(len(pts), np.float32)
+        assert oracle.oracle_dist_log_prob(C.byref(d), pts.ctypes.data, len(pts), out.ctypes.data) == 0
+        inf = np.isinf(ref)
+        assert np.array_equal(np.isinf(out), inf) and np.array_equal(out[inf], ref[inf].astype(np.float32)) and inf.sum() >= 2, i
+        # (shape < 1 at z = 0: the pdf itself is +inf, distribution.py:133-136 returns log(inf) = +inf)
+        want = ref[~inf].astype(np.float32)
+        ulp = np.spacing(np.abs(want))
+        assert np.all(np.abs(out[~inf].astype(np.float64) - want.astype(np.float64)) <= ulp), i
