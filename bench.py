@@ -93,6 +93,169 @@ def cpu_baseline(seconds_target=12.0):
     return out
 
 
+def _omp_cores():
+    cores = min(len(os.sched_getaffinity(0)), 16)            # the GPU box's CPU share for one GPU
+    os.environ["OMP_NUM_THREADS"] = str(cores)                # read by libgomp when the library is first loaded
+    return cores
+
+
+def cpu_baseline_sampler(workload, batch, seconds_target=12.0):
+    """The CPU checker's port of the workload's loop (oracle/glabc_oracle.c: GlobalMCMC.py:37-68, GLMALA.py:150-200, or
+    GLMCMC.py:58-104 on the g-and-k / the Gamma configuration), OpenMP over chains, on a bounded sample of the bench workload."""
+    import oracle_lib
+    from glabcmcmc_amd import _capi
+    model, lp, ip = descriptors(workload)
+    cores = _omp_cores()
+    L = oracle_lib.load()
+    d = model.theta_dim
+    gf = {"globalmcmc": 0.5, "glmala": 0.8, "gk": 0.9, "gamma": 0.9}[workload]
+    mala = _capi.Mala(0.3, 0.3 ** 2, EPS ** 2, 100, 0)
+    rng = np.random.default_rng(1)
+
+    def run(n, T):
+        if workload == "gk":
+            theta0 = (rng.random((n, 4)) * 10).astype(np.float32)
+            y0 = np.sort(rng.standard_normal((n, 8)) * 2 + 3, axis=1).astype(np.float32)
+        else:
+            theta0 = np.full((n, d), 1.4 if workload == "gamma" else 0.0, np.float32)
+            y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
+        hc = oracle_lib.HostChains(theta0, y0)
+        if workload == "glmala":
+            hc.add_mala_state()
+        hh = np.zeros((T, d, n), np.float32)
+        r, keep = oracle_lib.make_run(seed=1, step0=1, n_steps=T, gf=gf, batch=batch, history=hh)
+        cs = hc.struct()
+        if workload == "glmala":
+            assert L.oracle_glmala_init(C.byref(model), C.byref(cs)) == 0
+        elif workload != "globalmcmc":
+            assert L.oracle_init_weights(C.byref(model), C.byref(ip), C.byref(cs)) == 0
+        t = time.perf_counter()
+        if workload == "glmala":
+            rc = L.oracle_glmala_steps(C.byref(model), C.byref(ip), C.byref(mala), C.byref(cs), C.byref(r))
+        elif workload == "globalmcmc":
+            rc = L.oracle_globalmcmc_steps(C.byref(model), C.byref(lp), C.byref(ip), C.byref(cs), C.byref(r))
+        else:
+            rc = L.oracle_glmcmc_steps(C.byref(model), C.byref(lp), C.byref(ip), C.byref(cs), C.byref(r))
+        assert rc == 0
+        return n * T / (time.perf_counter() - t)
+
+    n = 4096 if workload == "glmala" else 16384
+    for _ in range(2):
+        rate = run(n, 4 if workload == "glmala" else 50)       # warm (threads, pages, clocks)
+    T = int(min(max(4, rate * seconds_target / n), 40000))
+    rate = run(n, T)
+    what = {"globalmcmc": "GlobalMCMC.py:37-68", "glmala": "GLMALA.py:150-200", "gk": "GLMCMC.py:58-104 on the g-and-k Model",
+            "gamma": "GLMCMC.py:58-104 with the Gamma prior / importance proposal"}[workload]
+    return {"value": rate, "unit": "chain-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/glabc_oracle.c (C port of %s), OpenMP over %d threads, %d chains x %d iterations of the bench "
+                      "workload" % (what, cores, n, T)}
+
+
+def cpu_baseline_nf(flow_desc, rows_sample, rows_log_prob, couplings, seconds_target=12.0):
+    """oracle_nf_sample + oracle_nf_log_prob (the checker's scalar restatement of the coupling stack) on a bounded number of
+    rows, one thread (the functions are not threaded)."""
+    import oracle_lib
+    L = oracle_lib.load()
+
+    def run(n_s, n_l):
+        z, lq = np.empty((2, n_s), np.float32), np.empty(n_s, np.float32)
+        x, lp = np.random.default_rng(0).standard_normal((2, n_l)).astype(np.float32), np.empty(n_l, np.float32)
+        t = time.perf_counter()
+        assert L.oracle_nf_sample(C.byref(flow_desc), None, 1234, 0, n_s, z.ctypes.data, lq.ctypes.data) == 0
+        assert L.oracle_nf_log_prob(C.byref(flow_desc), x.ctypes.data, n_l, lp.ctypes.data) == 0
+        return (n_s + n_l) / (time.perf_counter() - t)
+
+    rate = run(500, 100)
+    n = int(max(600, min(rate * seconds_target, rows_sample + rows_log_prob)))
+    n_l = max(1, int(n * rows_log_prob / float(rows_sample + rows_log_prob)))
+    rate = run(n - n_l, n_l)
+    return {"value": rate, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": "oracle_nf_sample + oracle_nf_log_prob (oracle/glabc_oracle.c, scalar), %d + %d rows, %d couplings"
+                      % (n - n_l, n_l, couplings)}
+
+
+def cpu_baseline_nf_train(flow_desc, couplings, seconds_target=12.0):
+    """oracle_nf_grad (forward_kld and its gradient, float32 states + double chain rule, scalar) on a bounded number of rows"""
+    import oracle_lib
+    from glabcmcmc_amd import _capi
+    L = oracle_lib.load()
+    gp = np.zeros(couplings * _capi.NF_COUPLING_FLOATS, np.float32)
+    gb, loss = np.zeros(4, np.float32), np.zeros(1, np.float32)
+
+    def run(n):
+        x = (np.random.default_rng(0).standard_normal((2, n)) * 0.8 + 0.3).astype(np.float32)
+        t = time.perf_counter()
+        assert L.oracle_nf_grad(C.byref(flow_desc), x.ctypes.data, n, gp.ctypes.data, gb.ctypes.data, loss.ctypes.data) == 0
+        return n / (time.perf_counter() - t)
+
+    rate = run(300)
+    n = int(max(300, rate * seconds_target))
+    return {"value": run(n), "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": "oracle_nf_grad (oracle/glabc_oracle.c: loss + gradient of forward_kld, scalar), %d rows, %d couplings; no "
+                      "Adam step" % (n, couplings)}
+
+
+def cpu_baseline_kde(kde_desc, n_centres, seconds_target=12.0):
+    """oracle_kde_log_prob (the checker's scalar logsumexp over the centres) on a bounded number of points"""
+    import oracle_lib
+    L = oracle_lib.load()
+
+    def run(n):
+        pts = np.random.default_rng(0).standard_normal((2, n)).astype(np.float32)
+        out = np.empty(n, np.float32)
+        t = time.perf_counter()
+        assert L.oracle_kde_log_prob(C.byref(kde_desc), pts.ctypes.data, n, out.ctypes.data) == 0
+        return float(n) * n_centres / (time.perf_counter() - t)
+
+    rate = run(200)
+    n = int(max(200, rate * seconds_target / n_centres))
+    return {"value": run(n), "unit": "pair-evaluations/s", "cores": 1, "kind": "port",
+            "sample": "oracle_kde_log_prob (oracle/glabc_oracle.c, scalar), %d points x %d centres" % (n, n_centres)}
+
+
+def lib_sha16():
+    import hashlib
+    from glabcmcmc_amd import _capi
+    h = hashlib.sha256()
+    with open(_capi.LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 22), b""):
+            h.update(chunk)
+    return h.hexdigest()[:16]
+
+
+def counted(workload, n, K, batch=None):
+    """profiles/r03_pmc_<workload>.json (tools/profile_workload.sh + summarise_workload.py): the rocprofv3 counters of exactly
+    this configuration -- used ONLY while the library that runs is the build they were taken with (SHA-256 of
+    libglabc_hip.so) and the launch shape is the same; anything else returns None instead of a stale number."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % workload)) as f:
+            p = json.load(f)
+        cfg = p["config"]
+        if p.get("lib_sha16") != lib_sha16() or cfg.get("chains") != n or cfg.get("iters_per_launch") != K:
+            return None
+        if batch is not None and cfg.get("batch_size") not in (None, batch):
+            return None
+        return p
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def valu_block(p, workload, kernel_ms):
+    """roofline.valu: counted vector instructions x this run's kernel time, against the guide's vector issue peak"""
+    d = p["derived"]
+    insts = p["raw_avg_per_launch"]["SQ_INSTS_VALU"]
+    wips = insts / (kernel_ms * 1e-3)
+    peak = 1024 * 2.4e9 / 2              # MI355X_MICROARCH.md: wave64 v_fma_f32 = 2 cycles on a SIMD-32; 1024 SIMDs at 2.4 GHz
+    return {"source": "profiles/r03_pmc_%s.json (rocprofv3 --pmc, library %s) + this run's kernel time" % (workload, p["lib_sha16"]),
+            "valu_insts_per_launch": insts, "valu_insts_per_group_step": d["valu_insts_per_group_step"],
+            "waves_per_launch": d.get("waves_per_launch"), "wave_insts_per_s": wips,
+            "simd_cycles_per_valu_inst": 1024 * 2.4e9 * kernel_ms * 1e-3 / insts,
+            "vector_peak_wave_insts_per_s": peak, "frac_of_vector_peak": wips / peak,
+            "note": "one group = 64 chains; simd_cycles_per_valu_inst = SIMD cycles (2.4 GHz nominal) per vector instruction issued "
+                    "on it, 2.0 at the guide's peak; the instruction mix of this path (v_mad_u64_u32, transcendental seeds, f64 in "
+                    "GLMALA) saturates near 3.0 - 3.3 (DESIGN.md 4.1)"}
+
+
 def bench_nf(args):
     """BASELINE configs[4]: RealNVP global proposal, 8 couplings x MLP[1,128,128,2], 65 536 chains x N=5 =
     327 680 rows per global step, on the f32 matrix cores.  One step = NF_model.sample(rows) + NF_model.log_prob
@@ -144,6 +307,13 @@ def bench_nf(args):
                         "frac": mfma_flop / (kernel_ms * 1e-3) / 1e12 / 157.3, "traffic": None,
                         "kernel": "glabc::nf_kernel<forward> + <inverse> (v_mfma_f32_32x32x2_f32)", "kernel_ms": kernel_ms,
                         "all_flop_TFLOPs": flop / (kernel_ms * 1e-3) / 1e12}}
+    pm = counted("nf", None, None)
+    if pm is not None and "mfma" in pm:
+        out["roofline"]["mfma_counters"] = {"source": "profiles/r03_pmc_nf.json (library %s)" % pm["lib_sha16"],
+                                            "per_kernel": pm["mfma"]["per_kernel"]}
+    if not args.no_cpu_baseline:
+        host_blob = blob.cpu().contiguous()                   # the checker reads host memory
+        out["cpu_baseline"] = cpu_baseline_nf(flow.descriptor(host_blob), rows, cur, args.couplings)
     print(json.dumps(out), flush=True)
 
 
@@ -211,6 +381,13 @@ def bench_nf_train(args):
                         "frac": mfma_flop / (grad_ms * 1e-3) / 1e12 / 157.3, "traffic": None,
                         "kernel": "glabc::nf_kernel<inverse> + glabc::nf_backward_kernel x couplings (v_mfma_f32_32x32x2_f32)",
                         "kernel_ms": grad_ms}}
+    pm = counted("nf_train", None, None)
+    if pm is not None and "mfma" in pm:
+        out["roofline"]["mfma_counters"] = {"source": "profiles/r03_pmc_nf_train.json (library %s)" % pm["lib_sha16"],
+                                            "per_kernel": pm["mfma"]["per_kernel"]}
+    if not args.no_cpu_baseline:
+        host_blob = flow.packed_params().cpu().contiguous()   # the checker reads host memory
+        out["cpu_baseline"] = cpu_baseline_nf_train(flow.descriptor(host_blob), args.couplings)
     print(json.dumps(out), flush=True)
 
 
@@ -237,7 +414,19 @@ def bench_kde(args):
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     algo_bytes = 4.0 * (3 * P + 3 * S + P)                      # points in, centres + log-weights in, densities out
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    cpu = None
+    if not args.no_cpu_baseline:
+        from glabcmcmc_amd import _capi
+        kd = kde.descriptor()
+        hx, hlw = kde._x.cpu().numpy().copy(), kde._log_w.cpu().numpy().copy()
+        hk = _capi.Kde()
+        hk.dim, hk.n_samples, hk.x, hk.log_w, hk.cum_q = kd.dim, kd.n_samples, hx.ctypes.data, hlw.ctypes.data, None
+        for j in range(kd.dim):
+            hk.bandwidth[j] = kd.bandwidth[j]
+        hk.sum_log_bw, hk.c_2pi = kd.sum_log_bw, kd.c_2pi
+        cpu = cpu_baseline_kde(hk, S)
     print(json.dumps({"metric": "KDE log-density pair evaluations/sec (points x centres), d = 2", "value": float(S) * P * args.steps / elapsed,
+                      "cpu_baseline": cpu,
                       "unit": "pair-evaluations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f32", "data": "synthetic",
@@ -302,6 +491,13 @@ def bench_glmcmc_nf(args):
                         "traffic": None, "kernel": "glabc::nf_kernel<forward, pairs> (pool draws)", "kernel_ms": None,
                         "note": "whole-loop rate: MFMA flops of the pool draws + log_prob refreshes over the wall time of the "
                                 "loop (pool weights, step kernels, host launches included); the kernel alone: --workload nf"}}
+    if not args.no_cpu_baseline:
+        host_blob = flow.cpu().packed_params().cpu().contiguous()
+        b = cpu_baseline_nf(flow.descriptor(host_blob), int(rows_per_iter), int(moved) + 1, args.couplings, seconds_target=10.0)
+        rows_per_chain_step = (rows_per_iter + moved) / float(n)
+        out["cpu_baseline"] = {"value": b["value"] / rows_per_chain_step, "unit": "chain-steps/s", "cores": 1, "kind": "port",
+                               "sample": "the loop's dominant part only -- the flow's pool draws and log_prob refreshes, %.2f rows per "
+                                         "chain-step -- through %s" % (rows_per_chain_step, b["sample"])}
     print(json.dumps(out), flush=True)
 
 
@@ -371,6 +567,9 @@ def bench_rtc(args):
                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
                         "note": "VALU-bound like the built-in kernel; the host picks the unit-Gaussian or the generic instantiation "
                                 "per launch as for the built-in Models (default schedule, the user's simulator inlined)"}}
+    if not args.no_cpu_baseline and N == NBATCH:
+        out["cpu_baseline"] = cpu_baseline()                  # the same workload: the simulator is the built-in one written as C
+        out["cpu_baseline"].pop("reference_like", None)
     print(json.dumps(out), flush=True)
 
 
@@ -417,6 +616,23 @@ def bench_aglmcmc(args):
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "kernel": "kde_log_prob_kernel<2> (dense points x centres logsumexp)", "kernel_ms": None,
                         "note": "whole-loop rate; the dominant kernel is VALU-bound O(points x centres) work, rated by --workload kde"}}
+    if not args.no_cpu_baseline:
+        from glabcmcmc_amd import KernelDensity, _capi
+        kde = KernelDensity(device="cuda", seed=1).fit(torch.randn(8192, 2), torch.rand(8192))
+        kd = kde.descriptor()
+        hx, hlw = kde._x.cpu().numpy().copy(), kde._log_w.cpu().numpy().copy()
+        hk = _capi.Kde()
+        hk.dim, hk.n_samples, hk.x, hk.log_w, hk.cum_q = kd.dim, kd.n_samples, hx.ctypes.data, hlw.ctypes.data, None
+        for j in range(kd.dim):
+            hk.bandwidth[j] = kd.bandwidth[j]
+        hk.sum_log_bw, hk.c_2pi = kd.sum_log_bw, kd.c_2pi
+        b = cpu_baseline_kde(hk, 8192, seconds_target=10.0)
+        # per chain-step the loop evaluates the density of ~N pool rows (every refresh: N step_size rows per chain per step_size
+        # global moves) against the 8192 centres
+        pairs = float(N) * 8192
+        out["cpu_baseline"] = {"value": b["value"] / pairs, "unit": "chain-steps/s", "cores": 1, "kind": "port",
+                               "sample": "the loop's dominant part only -- KernelDensity.log_prob of the pool rows, ~%d pair "
+                                         "evaluations per chain-step -- through %s" % (pairs, b["sample"])}
     print(json.dumps(out), flush=True)
 
 
@@ -578,6 +794,9 @@ def main():
     ap.add_argument("--batch", type=int, default=NBATCH, help="iSIR batch size N (default 5 = BASELINE configs[1]); above 16 the "
                     "wide kernel of glabc_wide.hip runs")
     ap.add_argument("--couplings", type=int, default=8, help="nf workload: number of couplings")
+    ap.add_argument("--fast-math", action="store_true", help="glmcmc workload: the OPT-IN fast-transcendental variant "
+                    "(glabc_run.math_mode = GLABC_MATH_FAST, include/glabc.h) -- another stream of normals, the same law; its own "
+                    "bench line, never the headline")
     ap.add_argument("--no-graph", action="store_true", help="callback workload: launch every iteration instead of replaying a "
                     "captured hipGraph (only an iteration without the sentinel check can be captured)")
     ap.add_argument("--no-sentinel", action="store_true", help="callback workload: skip the GLMCMC.py:92-93 redraw check "
@@ -629,17 +848,20 @@ def main():
     n, K = args.chains, args.iters
     seed = 20261003
 
-    # synthetic inputs, resident in HBM before the timed region: theta0 = 0 for every chain,
-    # y0 = |theta0| + sqrt(0.05) z  
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    # synthetic inputs, resident in HBM before the timed region: theta0 = 0 for every chain, y0 = |theta0| + sqrt(0.05) z
+    # (SURVEY.md 8d).  They are a function of the GLOBAL chain id -- one generator for the whole job, each rank keeps the rows
+    # of its shard -- so that a job gives the same chains however many ranks it is spread over (tests/test_parallel_gloo.py
+    # rehearses 4 ranks against 1 and requires identical pooled statistics).
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    lo, hi = rank * n, (rank + 1) * n
     if args.workload == "gk":
         from glabcmcmc_amd.examples.GK import GK_set
-        theta0 = torch.rand(n, 4, generator=g) * 10
-        torch.manual_seed(1234 + rank)
-        y0 = GK_set(0.6).generate_samples(theta0)
+        theta0 = (torch.rand(world * n, 4, generator=g) * 10)[lo:hi].contiguous()
+        z = torch.randn(world * n, 8, generator=g)[lo:hi].contiguous()
+        y0 = GK_set(0.6).simulate_from_noise(theta0, z)             # CPU tensors: the torch formula of examples/GK.py
     else:
         theta0 = torch.full((n, D), 1.4) if args.workload == "gamma" else torch.zeros(n, D)     # inside the Gamma prior's support
-        y0 = theta0.abs() + (0.05 ** 0.5) * torch.randn(n, D, generator=g)
+        y0 = theta0.abs() + (0.05 ** 0.5) * torch.randn(world * n, D, generator=g)[lo:hi]
     chains = engine.ChainBatch(theta0, y0, dev, chain0=rank * n)
     engine.init_weights(model, ip, chains)
     hist = None if args.no_history else torch.empty(K, Dw, n, dtype=torch.float32, device=dev)
@@ -662,7 +884,8 @@ def main():
             entry = "glabc_globalmcmc_steps" if args.workload == "globalmcmc" else "glabc_glmcmc_steps"
             engine.run_steps(entry, model, lp, ip, chains, K, 1 + step_idx[0] * K, seed, gf, args.batch,
                              history=hist, moments=None if args.no_moments else mom, steps_per_launch=K,
-                             lanes_per_chain=args.lanes, debug_flags=args.debug_flags)
+                             lanes_per_chain=args.lanes, debug_flags=args.debug_flags,
+                             math_mode=_capi.MATH_FAST if args.fast_math else _capi.MATH_EXACT)
             if args.no_moments:
                 mom.steps += K
         step_idx[0] += 1
@@ -708,53 +931,19 @@ def main():
         ok = torch.isfinite(esjd_all)
         # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
         # read correction applied) for exactly this configuration: profiles/r01_f_pmc_summary.json
+        # the launch geometry glabc_glmcmc_steps picks (csrc/glabc_hip.hip run_sampler): teams of wavefronts for launches of
+        # 16 384 .. 131 072 chains when the caller leaves the geometry to the library
+        team_geometry = args.workload in ("glmcmc", "gk") and 2 <= args.batch <= 16 and args.lanes == 0 and \
+            not (args.debug_flags & 2) and ((args.debug_flags & 4) or 16384 <= n <= 131072)
         traffic, valu = None, None
-        try:
-            pmc_file = "r02_pmc_summary.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) \
-                else "r01_f_pmc_summary.json"
-            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                pmc = json.load(f)
-            if args.workload == "glmcmc" and pmc["config"] == {"chains": n, "iters_per_launch": K,
-                                                               "history": not args.no_history}:
-                traffic = pmc["hbm_traffic_bytes_per_launch"]["total"]
-                per_step = pmc["derived"]["valu_insts_per_wave_step"]
-                wave_insts_per_s = per_step * (n / 64.0) * K / (kernel_ms * 1e-3)      # live kernel time x counted instructions
-                valu = {"source": "profiles/%s (rocprofv3 --pmc) + this run's kernel time" % pmc_file,
-                        "valu_insts_per_wave_step": per_step,
-                        "valu_active_fraction": pmc["derived"]["valu_active_fraction"],
-                        "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
-                        "wave_insts_per_s": wave_insts_per_s,
-                        # measured ceilings (tools/ubench/valu_peak.hip): a SIMD retires 1.0e9 simple wave64
-                        # VALU ops/s (v_add_u32, v_xor_b32, v_mul_f32; >= 2 waves/SIMD), and THIS kernel's instruction mix
-                        # (v_pk_* 5.4, v_mad_u64_u32 4.2, v_fma_f32 3.2 cycles) saturates at 6.4e11 wave-insts/s on the
-                        # chip (524 288 chains = 8 waves/SIMD); one wave per SIMD -- the 65 536-chain shape -- cannot
-                        # issue faster than one instruction per ~4.7 cycles.
-                        # against the guide (MI355X_MICROARCH.md constants table: v_fma_f32 wave64 = 2 cycles on a SIMD-32,
-                        # 4 for one wave alone): 1024 SIMDs x 2.4 GHz / 2 cycles.  The 65 536-chain shape is ONE wave
-                        # per SIMD, whose own ceiling is half of that.
-                        "vector_peak_wave_insts_per_s": 1024 * 2.4e9 / 2,
-                        "frac_of_vector_peak": wave_insts_per_s / (1024 * 2.4e9 / 2),
-                        "one_wave_per_simd_peak_wave_insts_per_s": 1024 * 2.4e9 / 4,
-                        "frac_of_one_wave_peak": wave_insts_per_s / (1024 * 2.4e9 / 4) if n <= 65536 else None,
-                        "issue_peak_wave_insts_per_s": 1024 * 1.0e9,
-                        "issue_frac": wave_insts_per_s / (1024 * 1.0e9),
-                        "mix_saturated_wave_insts_per_s": 6.4e11,
-                        "mix_frac": wave_insts_per_s / 6.4e11}
-            if args.workload == "glmala":                  # the counted instructions of glmala_kernel x this run's kernel time
-                with open(os.path.join(ROOT, "profiles", "r02_pmc_glmala.json")) as f:
-                    pg = json.load(f)
-                if pg["config"] == {"chains": n, "iters_per_launch": K}:
-                    per_step = pg["derived"]["valu_insts_per_wave_step"]
-                    wips = per_step * (n / 64.0) * K / (kernel_ms * 1e-3)
-                    valu = {"source": "profiles/r02_pmc_glmala.json (rocprofv3 --pmc) + this run's kernel time",
-                            "valu_insts_per_wave_step": per_step, "wave_insts_per_s": wips,
-                            "valu_active_fraction": pg["derived"].get("valu_active_fraction"),
-                            "cycles_per_valu_inst": pg["derived"].get("cycles_per_valu_inst"),
-                            "vector_peak_wave_insts_per_s": 1024 * 2.4e9 / 2, "frac_of_vector_peak": wips / (1024 * 2.4e9 / 2)}
-        except (OSError, KeyError, ValueError):
-            pass
+        p = counted(args.workload + ("_fast" if args.fast_math else ""), n, K, args.batch if args.workload in ("glmcmc", "gk", "gamma") else None)
+        if p is not None and args.lanes == 0 and args.debug_flags == 0 and not args.no_history and not args.no_moments:
+            valu = valu_block(p, args.workload, kernel_ms)
+            if "hbm_traffic_bytes_per_launch" in p:
+                traffic = p["hbm_traffic_bytes_per_launch"]["total"]
         out = {
-            "metric": "MH accept-steps/sec (whole node) + ESJD, 65 536 chains, Mixture_set dim=2",
+            "metric": "MH accept-steps/sec (whole node) + ESJD, 65 536 chains, Mixture_set dim=2" +
+                      (" -- OPT-IN fast-transcendental variant (GLABC_MATH_FAST), not the headline" if args.fast_math else ""),
             "value": value, "unit": "chain-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -768,7 +957,7 @@ def main():
                                     "gamma": "GLMCMC iSIR N=%d gf=0.9, Mixture_set eps=0.05 d=2 with a Gamma(2,1) prior and a "
                                              "Gamma(4,3) importance proposal (distribution.py:90-137) in the fused kernel" % args.batch}[args.workload],
                        "chains_per_gpu": n, "iters_per_step": K, "batch_size": args.batch if args.workload in ("glmcmc", "gk", "gamma") else NBATCH,
-                       "history": not args.no_history,
+                       "history": not args.no_history, "math_mode": "fast" if args.fast_math else "exact",
                        "lanes_per_chain": args.lanes or "auto",
                        "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "esjd_mean": float(esjd_all[ok].double().mean()), "esjd_nan_frac": float(1.0 - ok.double().mean()),
@@ -777,16 +966,20 @@ def main():
             "moment_iters": steps_all,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {"glmcmc": "glabc::sampler_kernel<GLMCMC, D=2, N=%d>" % args.batch if args.batch <= 16
-                                    else "glabc::wide_kernel<D=2, L> N=%d" % args.batch,
+                         "kernel": {"glmcmc": ("glabc::team_sampler_kernel<D=2, N=%d, %d wavefronts per 64 chains>"
+                                               % (args.batch, 3 if n <= 65536 and args.batch >= 3 else 2)
+                                               if team_geometry else "glabc::sampler_kernel<GLMCMC, D=2, N=%d>" % args.batch)
+                                    if args.batch <= 16 else "glabc::wide_kernel<D=2, L> N=%d" % args.batch,
                                     "globalmcmc": "glabc::sampler_kernel<GLOBAL, D=2, N=1>",
-                                    "glmala": "glabc::glmala_kernel<D=2, N=5>",
-                                    "gk": "glabc::sampler_kernel<GLMCMC, D=4, YD=8, N=5>",
+                                    "glmala": "glabc::glmala_team_kernel<N=5, 2 wavefronts per 64 chains>" if n < 131072 and args.lanes in (0, 2)
+                                    else "glabc::glmala_kernel<D=2, N=5>",
+                                    "gk": "glabc::team_sampler_kernel<D=4, YD=8, N=%d>" % args.batch if team_geometry
+                                    else "glabc::sampler_kernel<GLMCMC, D=4, YD=8, N=%d>" % args.batch,
                                     "gamma": "glabc::sampler_kernel<GLMCMC, D=2, N=%d, VAR_GAMMA>" % args.batch}[args.workload], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_chain_step": algo_bytes / (n * K),
                          "valu": valu,
-                         "note": {"glmcmc": "the step is VALU-issue-bound, not HBM-bound: ~1260 vector instructions per chain-"
+                         "note": {"glmcmc": "the step is VALU-bound, not HBM-bound: ~1300 - 1500 vector instructions per chain-"
                                             "step against 8 algorithmic bytes (Philox + Box-Muller + densities); see DESIGN.md",
                                   "globalmcmc": "VALU-bound like the GLMCMC step (one candidate per iteration); see DESIGN.md 4.1",
                                   "glmala": "VALU-bound: a MALA move costs 400 simulations for its finite-difference gradient "
@@ -795,8 +988,10 @@ def main():
                                   "gamma": "VALU-bound, float64: per candidate two Marsaglia-Tsang rejection loops (double log / sqrt) and four "
                                            "double-precision log(pdf) evaluations; see DESIGN.md"}[args.workload]},
         }
-        if not args.no_cpu_baseline and world == 1 and args.workload == "glmcmc":
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline() if args.workload == "glmcmc" and args.batch == NBATCH and not args.fast_math else \
+                cpu_baseline_sampler(args.workload, NBATCH if args.workload in ("globalmcmc", "glmala") else args.batch) \
+                if args.workload != "glmcmc" else None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -101,6 +101,10 @@ struct StepArgs {
     const float* tape_z;
     int32_t tape_nprop;
     int32_t exact_index;          // GLABC_DEBUG_EXACT_INDEX
+    // GLABC_MATH_FAST only: where the kernel records the draws it used (glabc_draws_out), or NULL
+    float* dump_u;
+    double* dump_r;
+    float* dump_z;
 };
 
 // ---- torch.sum association over a contiguous float32 row (GLMCMC.py:82) ---------
@@ -445,7 +449,7 @@ GLABC_DEV void model_simulate(const StepArgs<D, YD>& a, const float (&theta)[D],
 // LEAN_SQRT: the caller knows every |y_obs_j| >= 2^-6, so a difference y_j - y_obs_j is 0 or at least 2^-31 in
 // magnitude and the sum of squares is 0 or >= 2^-62 -- the domain on which glabc_sqrtf_normal is the correctly
 // rounded square root (8 instructions less than the general expansion, five times per step)
-template <int D, int YD, bool LEAN_SQRT = false>
+template <int D, int YD, bool LEAN_SQRT = false, bool FAST = false>
 GLABC_DEV float model_log_kernel(const StepArgs<D, YD>& a, const float (&y)[YD])
 {
     float t[YD];
@@ -455,6 +459,10 @@ GLABC_DEV float model_log_kernel(const StepArgs<D, YD>& a, const float (&y)[YD])
         t[j] = d * d;
     }
     const float ss = aten_rowsum<YD>(t);
+    if constexpr (FAST) {                                               // GLABC_MATH_FAST: v_sqrt_f32, v_rcp_f32
+        const float e = __builtin_amdgcn_sqrtf(ss) * __builtin_amdgcn_rcpf(a.kern_scale);
+        return a.kern_c0 - (a.kern_log_scale + 0.5f * (e * e));
+    }
     float dis = LEAN_SQRT ? glabc_sqrtf_normal(ss) : __builtin_sqrtf(ss);
     float e;
     if constexpr (LEAN_SQRT) {
@@ -475,6 +483,28 @@ GLABC_DEV float model_log_kernel(const StepArgs<D, YD>& a, const float (&y)[YD])
 struct Rng {
     uint32_t c0, c1, k0, k1;
 };
+
+// ---- GLABC_MATH_FAST (include/glabc.h): the hardware's transcendental instructions, device only ------------------------
+// v_log_f32 is log2, v_exp_f32 is 2^x, v_sin_f32 / v_cos_f32 take their argument in revolutions (sin(2 pi x)), ~1 ulp each.
+GLABC_DEV void fast_normal_pair(uint32_t a, uint32_t b, float* z0, float* z1)
+{
+    const float u1 = glabc_uniform_pos_f32(a);                          // (0, 1]
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), ln = ln 2 * log2
+    const float u2 = glabc_uniform_f32(b);                              // [0, 1) revolutions
+    *z0 = rad * __builtin_amdgcn_cosf(u2);
+    *z1 = rad * __builtin_amdgcn_sinf(u2);
+}
+// exp: v_exp_f32 flushes results below 2^-126 to zero; a hopeless chain's iSIR weights are ALL that small (far from the
+// observation every K(y) is a large negative number) and the reference still resamples among them (torch.exp underflows
+// gradually), so the small range is scaled: 2^(t + 64) * 2^-64, the multiplication rounds into the denormals correctly.
+GLABC_DEV float fast_expf(float x)
+{
+    const float t = x * 1.4426950408889634f;                            // exp(-inf) = 0, NaN stays NaN
+    const bool tiny = t < -126.0f;
+    const float r = __builtin_amdgcn_exp2f(tiny ? t + 64.0f : t);
+    return tiny ? r * 0x1p-64f : r;
+}
+GLABC_DEV float fast_logf(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }       // log(0) = -inf
 
 // ---- lane-group exchange -----------------------------------------------------------------
 // Groups are 1, 2 or 4 adjacent lanes, i.e. they sit inside one DPP quad: a value held by

@@ -445,7 +445,7 @@ static int pack_common(int algo, const glabc_dist* local, const glabc_dist* glob
     if (io->theta_dim < 1 || io->y_dim < 1 || io->noise_dim < 0) return GLABC_ERR_DIM;
     if (io->n_prop < 1 || (algo == GLABC_ALGO_GLOBALMCMC && io->n_prop != 1)) return GLABC_ERR_ARG;
     if ((int64_t)io->n_prop * c->n_chains > (int64_t)1 << 40) return GLABC_ERR_ARG;
-    if (r->n_steps != 1 || r->tape) return GLABC_ERR_ARG;
+    if (r->n_steps != 1 || r->tape || r->math_mode != GLABC_MATH_EXACT || r->dump_draws) return GLABC_ERR_ARG;
     if (c->n_chains < 0 || c->stride < c->n_chains || c->chain0 < 0) return GLABC_ERR_ARG;
     if (!c->theta || !c->y) return GLABC_ERR_NULL;
     if (!(r->global_frequency >= 0.0f) && !(r->global_frequency < 0.0f)) return GLABC_ERR_ARG;

@@ -642,6 +642,15 @@ static int check_run(const glabc_model* m, const glabc_dist* local, const glabc_
     }
     if ((uint64_t)r->step0 + (uint64_t)r->n_steps > 0xFFFFFFFFull) return GLABC_ERR_ARG;
     if (r->step0_device) return GLABC_ERR_ARG;                  // the split-phase entry points only
+    if (r->math_mode != GLABC_MATH_EXACT && r->math_mode != GLABC_MATH_FAST) return GLABC_ERR_ARG;
+    if (r->math_mode == GLABC_MATH_FAST) {                      // the opt-in variant: where a team kernel exists (include/glabc.h)
+        if (!isir || r->tape || gamma || m->sim_kind != GLABC_SIM_ABS_GAUSS || m->theta_dim > 4 || r->batch_size < 2 ||
+            r->batch_size > GLABC_MAX_BATCH || r->lanes_per_chain != 0)
+            return GLABC_ERR_ARG;
+        if (r->dump_draws && (!r->dump_draws->u || !r->dump_draws->r || !r->dump_draws->z)) return GLABC_ERR_NULL;
+    } else if (r->dump_draws) {
+        return GLABC_ERR_ARG;
+    }
     return GLABC_OK;
 }
 
@@ -683,8 +692,9 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
     // Team geometry (glabc_team.h): two wavefronts per 64 chains, for launches that would otherwise leave the SIMDs with at most
     // two wavefronts of sampler_kernel each.  Chosen when the caller leaves the geometry to the library.
     const bool gamma = m->prior.kind == GLABC_DIST_GAMMA || global->kind == GLABC_DIST_GAMMA;      // VAR_GAMMA: one lane per chain
-    if (algo == ALGO_GLMCMC && !r->tape && !gamma && !(r->debug_flags & GLABC_DEBUG_NO_TEAM) &&
-        ((r->debug_flags & GLABC_DEBUG_TEAM) || (r->lanes_per_chain == 0 && c->n_chains >= 64 * 256 && c->n_chains <= 2 * 1024 * 64))) {
+    const bool fast = r->math_mode == GLABC_MATH_FAST;      // runs the team kernels whatever the launch size
+    if (algo == ALGO_GLMCMC && !r->tape && !gamma && (fast || !(r->debug_flags & GLABC_DEBUG_NO_TEAM)) &&
+        (fast || (r->debug_flags & GLABC_DEBUG_TEAM) || (r->lanes_per_chain == 0 && c->n_chains >= 64 * 256 && c->n_chains <= 2 * 1024 * 64))) {
         int prio = 1;                                       // the main wavefront carries the serial part of an iteration
         if (const char* e = std::getenv("GLABC_TEAM_PRIO")) prio = std::max(0, std::min(3, std::atoi(e)));
         // wavefronts per 64 chains: enough for about three wavefronts per SIMD (1024 SIMDs)
@@ -694,17 +704,17 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
         rc = GLABC_ERR_ARG;
         for (; nw >= 2 && rc == GLABC_ERR_ARG; --nw) {      // fewer wavefronts when the batch is too small to split that far
             if (m->sim_kind == GLABC_SIM_GK) {
-                rc = launch_team_dim<4, 8>(r->batch_size, nw, pack_args<4, 8>(m, local, global, c, r), prio, s);
+                rc = launch_team_dim<4, 8>(r->batch_size, nw, pack_args<4, 8>(m, local, global, c, r), prio, fast, s);
             } else {
                 switch (m->theta_dim) {
-#define GLABC_TEAM_CASE(d) case d: rc = launch_team_dim<d, d>(r->batch_size, nw, pack_args<d>(m, local, global, c, r), prio, s); break;
+#define GLABC_TEAM_CASE(d) case d: rc = launch_team_dim<d, d>(r->batch_size, nw, pack_args<d>(m, local, global, c, r), prio, fast, s); break;
                     GLABC_TEAM_CASE(1) GLABC_TEAM_CASE(2) GLABC_TEAM_CASE(3) GLABC_TEAM_CASE(4)
 #undef GLABC_TEAM_CASE
                 default: nw = 0; break;
                 }
             }
         }
-        if (rc != GLABC_ERR_ARG) {                          // GLABC_ERR_ARG: no team kernel for this configuration
+        if (rc != GLABC_ERR_ARG || fast) {                  // GLABC_ERR_ARG: no team kernel for this configuration (fast math: refused)
             if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
             return rc;
         }
@@ -713,7 +723,7 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
     // Two builds of the same kernels: up to two waves per SIMD (131 072 lanes on this part) a launch is latency-bound
     // and runs the max-ilp schedule (217 VGPRs, 6 % faster at 65 536 chains); larger launches need the occupancy
     // of the default schedule (126 VGPRs).  The tape variant and lane groups exist in the default objects only.
-    const bool ilp = lanes == 1 && !r->tape && !gamma && c->n_chains <= 2 * 1024 * 64;
+    const bool ilp = lanes == 1 && !r->tape && !gamma && c->n_chains <= 2 * 1024 * 64 && !(r->debug_flags & GLABC_DEBUG_DEFAULT_SCHEDULE);
     if (m->sim_kind == GLABC_SIM_GK) {
         rc = launch_sampler_dim<4, 8, SCHED_DEFAULT>(algo, r->batch_size, lanes, pack_args<4, 8>(m, local, global, c, r), s);
     } else {
@@ -800,7 +810,7 @@ __attribute__((visibility("default"))) int glabc_glmala_steps(const glabc_model*
         return GLABC_ERR_ARG;
     if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
     if (r->moments && (!r->moments->sum_theta || !r->moments->sum_outer || !r->moments->sum_jump)) return GLABC_ERR_NULL;
-    if (r->tape) return GLABC_ERR_ARG;
+    if (r->tape || r->math_mode != GLABC_MATH_EXACT || r->dump_draws) return GLABC_ERR_ARG;
     if (r->lanes_per_chain < 0 || r->lanes_per_chain > 2) return GLABC_ERR_ARG;      // wavefronts per 64 chains (theta_dim 2)
     if ((uint64_t)r->step0 + (uint64_t)r->n_steps > 0xFFFFFFFFull) return GLABC_ERR_ARG;
     if (c->n_chains == 0 || r->n_steps == 0) return GLABC_OK;
@@ -963,7 +973,7 @@ __attribute__((visibility("default"))) int glabc_glmcmc_nf_step(const glabc_mode
     if (c->n_chains < 0 || c->stride < c->n_chains || c->chain0 < 0 || pool->step_size < 1) return GLABC_ERR_ARG;
     if (r->n_steps != 1 || r->batch_size < 1 || r->batch_size > GLABC_MAX_BATCH) return GLABC_ERR_ARG;
     if (r->history && r->hist_stride < c->n_chains) return GLABC_ERR_ARG;
-    if (r->tape || r->moments || r->global_frequency_per_chain) return GLABC_ERR_ARG;
+    if (r->tape || r->moments || r->global_frequency_per_chain || r->math_mode != GLABC_MATH_EXACT || r->dump_draws) return GLABC_ERR_ARG;
     if ((pool->moved_idx == nullptr) != (pool->n_moved == nullptr)) return GLABC_ERR_NULL;
     if (c->n_chains > 0x7fffffff) return GLABC_ERR_ARG;
     if (c->n_chains == 0) return GLABC_OK;

@@ -87,6 +87,11 @@ inline StepArgs<D, YD> pack_args_rinv(const glabc_model* m, const glabc_dist* lo
             a.sum_outer = r->moments->sum_outer;
             a.sum_jump = r->moments->sum_jump;
         }
+        if (r->math_mode == GLABC_MATH_FAST && r->dump_draws) {
+            a.dump_u = r->dump_draws->u;
+            a.dump_r = r->dump_draws->r;
+            a.dump_z = r->dump_draws->z;
+        }
         if (r->tape) {
             a.tape_u = r->tape->u;
             a.tape_r = r->tape->r;

@@ -53,9 +53,12 @@ struct TeamCand {                          // one iteration's candidates of the 
 };
 
 // candidate j of (chain, step): chain_step's slot body.  FIRST = candidate 0, which is the local move's proposal when `loc`
-template <int D, int YD, int VAR, bool FIRST>
+// FAST = GLABC_MATH_FAST (include/glabc.h): hardware transcendentals; the draws used are recorded when a.dump_z is set (`row` =
+// chain * n_steps + iteration of this launch)
+template <int D, int YD, int VAR, bool FIRST, bool FAST = false>
 GLABC_DEV void team_candidate(const StepArgs<D, YD>& a, const Rng& rng, uint32_t step, int j, bool loc, const Chain<D, YD>& c,
-                              float (&th)[D], float (&yy)[YD], float& lw, float& pr, float& kk, float& wl)
+                              float (&th)[D], float (&yy)[YD], float& lw, float& pr, float& kk, float& wl, int64_t row = 0,
+                              int n_prop = 0, bool dump = false)
 {
     constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
     constexpr int DP = D + (D & 1);
@@ -75,11 +78,23 @@ GLABC_DEV void team_candidate(const StepArgs<D, YD>& a, const Rng& rng, uint32_t
     const bool uni = lc ? l_uni : g_uni;
     float nrm[2 * ((M + 1) / 2)], e[D], s[ND];
 #pragma unroll
-    for (int i = 0; 2 * i < M; ++i) glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
+    for (int i = 0; 2 * i < M; ++i) {
+        if constexpr (FAST) fast_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
+        else glabc_normal_pair(w[2 * i], w[2 * i + 1], &nrm[2 * i], &nrm[2 * i + 1]);
+    }
 #pragma unroll
     for (int i = 0; i < D; ++i) e[i] = (!GU && uni) ? glabc_uniform_f32(w[i]) : nrm[i];
 #pragma unroll
     for (int i = 0; i < ND; ++i) s[i] = nrm[DP + i];
+    if constexpr (FAST) {
+        if (dump) {                                                           // glabc_draws_out.z[chain][t][j][D + YD]
+            float* z = a.dump_z + (row * n_prop + j) * (D + ND);
+#pragma unroll
+            for (int i = 0; i < D; ++i) z[i] = e[i];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) z[D + i] = s[i];
+        }
+    }
 #pragma unroll
     for (int q = 0; q < D; ++q) {
         const float p0 = lc ? a.local.p0[q] : a.global.p0[q];
@@ -98,15 +113,15 @@ GLABC_DEV void team_candidate(const StepArgs<D, YD>& a, const Rng& rng, uint32_t
     }
     model_simulate<D, YD>(a, th, s, yy);
     pr = dist_log_prob<D, GU>(a.prior, th);
-    kk = model_log_kernel<D, YD, GU>(a, yy);
+    kk = model_log_kernel<D, YD, GU, FAST>(a, yy);
     lw = (pr + kk) - lq;                                                      // GLMCMC.py:74
-    const float v = glabc_expf(lw);                                           // GLMCMC.py:78
+    const float v = FAST ? fast_expf(lw) : glabc_expf(lw);                    // GLMCMC.py:78
     wl = (v != v) ? 0.0f : v;                                                 // GLMCMC.py:80-81
 }
 
 // helper wavefront: candidates LO .. HI-1 of every iteration, one iteration ahead of the main wavefront
-template <int D, int YD, int N, int VAR, int NA, int LO, int HI>
-GLABC_DEV void team_helper(const StepArgs<D, YD>& a, const Rng& rng, int lane, TeamCand<D, YD, N - NA> (&buf)[2])
+template <int D, int YD, int N, int VAR, int NA, int LO, int HI, bool FAST>
+GLABC_DEV void team_helper(const StepArgs<D, YD>& a, const Rng& rng, int lane, TeamCand<D, YD, N - NA> (&buf)[2], int64_t chain, bool valid)
 {
     Chain<D, YD> none;                                     // never read: FIRST = false
 #pragma unroll 1
@@ -116,7 +131,8 @@ GLABC_DEV void team_helper(const StepArgs<D, YD>& a, const Rng& rng, int lane, T
 #pragma unroll
         for (int j = LO; j < HI; ++j) {
             float th[D], yy[YD], lw, pr, kk, wl;
-            team_candidate<D, YD, VAR, false>(a, rng, step, j, false, none, th, yy, lw, pr, kk, wl);
+            team_candidate<D, YD, VAR, false, FAST>(a, rng, step, j, false, none, th, yy, lw, pr, kk, wl,
+                                                    chain * (int64_t)a.n_steps + t, N, FAST && valid && a.dump_z != nullptr);
             o.wl[j - NA][lane] = wl;
             o.lw[j - NA][lane] = lw;
             o.pr[j - NA][lane] = pr;
@@ -130,7 +146,7 @@ GLABC_DEV void team_helper(const StepArgs<D, YD>& a, const Rng& rng, int lane, T
     }
 }
 
-template <int D, int YD, int N, int VAR, int NW>
+template <int D, int YD, int N, int VAR, int NW, bool FAST = false>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) team_sampler_kernel(const StepArgs<D, YD> a, int prio)
 {
     constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
@@ -149,12 +165,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
     rng.k1 = a.seed_hi;
 
     if (wave != 0) {                                       // ---- helpers: a pure function of (seed, chain id, iteration, j) ----
-        if (wave == 1) team_helper<D, YD, N, VAR, NA, team_helper_first(N, NW, 0), team_helper_first(N, NW, 1)>(a, rng, lane, buf);
+        if (wave == 1) team_helper<D, YD, N, VAR, NA, team_helper_first(N, NW, 0), team_helper_first(N, NW, 1), FAST>(a, rng, lane, buf, i, valid);
         if constexpr (NW >= 3) {
-            if (wave == 2) team_helper<D, YD, N, VAR, NA, team_helper_first(N, NW, 1), team_helper_first(N, NW, 2)>(a, rng, lane, buf);
+            if (wave == 2) team_helper<D, YD, N, VAR, NA, team_helper_first(N, NW, 1), team_helper_first(N, NW, 2), FAST>(a, rng, lane, buf, i, valid);
         }
         if constexpr (NW >= 4) {
-            if (wave == 3) team_helper<D, YD, N, VAR, NA, team_helper_first(N, NW, 2), team_helper_first(N, NW, 3)>(a, rng, lane, buf);
+            if (wave == 3) team_helper<D, YD, N, VAR, NA, team_helper_first(N, NW, 2), team_helper_first(N, NW, 3), FAST>(a, rng, lane, buf, i, valid);
         }
         return;
     }
@@ -173,9 +189,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
     c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
     c.gf = a.gf_chain ? a.gf_chain[i] : a.gf;
     refresh_cache<D, YD>(a, c);
+    if constexpr (FAST) c.kern = model_log_kernel<D, YD, false, true>(a, c.y);             // the cached K(y_old) in the arithmetic of the candidates
     c.lw_cur = (c.flags & GLABC_FLAG_LOCAL) ? (c.prior + c.kern) - c.q : c.log_w;          // GLMCMC.py:60-64
     {
-        const float v = glabc_expf(c.lw_cur);
+        const float v = FAST ? fast_expf(c.lw_cur) : glabc_expf(c.lw_cur);
         c.w_cur = (v != v) ? 0.0f : v;                                                      // GLMCMC.py:78-81
     }
     constexpr int TRI = D * (D + 1) / 2;
@@ -202,19 +219,28 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
         // step head, GLMCMC.py:59-65,98 (chain_step take_head)
         glabc_u32x4 hd = glabc_philox4x32_10(rng.c0, rng.c1, step, 0u, rng.k0, rng.k1);
         const float ub = glabc_uniform_f32(hd.v[0]), ua = glabc_uniform_f32(hd.v[1]);
-        const float log_u = (ua == 0.0f) ? -__builtin_inff() : glabc_logf_normal(ua);
+        const float log_u = FAST ? fast_logf(ua) : ((ua == 0.0f) ? -__builtin_inff() : glabc_logf_normal(ua));
         const bool is_global = ub < c.gf;
+        const int64_t row = i * (int64_t)a.n_steps + t;
+        const bool dump = FAST && valid && a.dump_z != nullptr;
+        if constexpr (FAST) {
+            if (dump) {                                                           // glabc_draws_out.u / .r
+                a.dump_u[2 * row] = ub;
+                a.dump_u[2 * row + 1] = ua;
+                a.dump_r[row] = glabc_uniform_f64(hd.v[2], hd.v[3]);
+            }
+        }
         if (is_global) {
             if (c.flags & GLABC_FLAG_LOCAL) c.log_w = c.lw_cur;                   // GLMCMC.py:60-64
             c.flags &= ~GLABC_FLAG_LOCAL;                                         // GLMCMC.py:65
         }
         // own candidates
         float th[NA][D], yy[NA][YD], lw[NA], pr[NA], kk[NA], wl[NA];
-        team_candidate<D, YD, VAR, true>(a, rng, step, 0, !is_global, c, th[0], yy[0], lw[0], pr[0], kk[0], wl[0]);
+        team_candidate<D, YD, VAR, true, FAST>(a, rng, step, 0, !is_global, c, th[0], yy[0], lw[0], pr[0], kk[0], wl[0], row, N, dump);
         const bool acc_mh = log_u < (((pr[0] + kk[0]) - c.prior) - c.kern);       // GLMCMC.py:96-99
 #pragma unroll
         for (int r = 1; r < NA; ++r)
-            team_candidate<D, YD, VAR, false>(a, rng, step, r, false, c, th[r], yy[r], lw[r], pr[r], kk[r], wl[r]);
+            team_candidate<D, YD, VAR, false, FAST>(a, rng, step, r, false, c, th[r], yy[r], lw[r], pr[r], kk[r], wl[r], row, N, dump);
 
         __syncthreads();                                                          // the helper's candidates of iteration t
         const TeamCand<D, YD, NH>& in = buf[t & 1];
@@ -357,7 +383,7 @@ constexpr bool team_config_ok(int d, int yd, int n, int nw)
 // host-side launcher of one (theta_dim, y_dim); defined in glabc_team_dim.hip.  nw = wavefronts per 64 chains (2, 3 or 4).
 // GLABC_ERR_ARG when the configuration has no such team kernel (too few candidates, or candidates beyond the LDS budget).
 template <int D, int YD>
-int launch_team_dim(int n_batch, int nw, const StepArgs<D, YD>& a, int prio, hipStream_t stream);
+int launch_team_dim(int n_batch, int nw, const StepArgs<D, YD>& a, int prio, bool fast, hipStream_t stream);
 #endif
 
 }  // namespace glabc

@@ -12,15 +12,15 @@
 
 namespace glabc {
 
-template <int D, int YD, int N, int NW>
+template <int D, int YD, int N, int NW, bool FAST>
 static int launch_team(const StepArgs<D, YD>& a, int prio, hipStream_t s)
 {
-    if constexpr (team_config_ok(D, YD, N, NW)) {
+    if constexpr (team_config_ok(D, YD, N, NW) && (!FAST || YD == D)) {
         const unsigned grid = (unsigned)((a.n_chains + 63) / 64);
         if (gauss_unit_config<D, YD>(a))
-            hipLaunchKernelGGL((team_sampler_kernel<D, YD, N, (YD == D ? VAR_GAUSS_UNIT : VAR_GENERIC), NW>), dim3(grid), dim3(64 * NW), 0, s, a, prio);
+            hipLaunchKernelGGL((team_sampler_kernel<D, YD, N, (YD == D ? VAR_GAUSS_UNIT : VAR_GENERIC), NW, FAST>), dim3(grid), dim3(64 * NW), 0, s, a, prio);
         else
-            hipLaunchKernelGGL((team_sampler_kernel<D, YD, N, VAR_GENERIC, NW>), dim3(grid), dim3(64 * NW), 0, s, a, prio);
+            hipLaunchKernelGGL((team_sampler_kernel<D, YD, N, VAR_GENERIC, NW, FAST>), dim3(grid), dim3(64 * NW), 0, s, a, prio);
         return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
     } else {
         return GLABC_ERR_ARG;
@@ -28,22 +28,29 @@ static int launch_team(const StepArgs<D, YD>& a, int prio, hipStream_t s)
 }
 
 template <int D, int YD, int N>
-static int launch_team_nw(int nw, const StepArgs<D, YD>& a, int prio, hipStream_t s)
+static int launch_team_nw(int nw, const StepArgs<D, YD>& a, int prio, bool fast, hipStream_t s)
 {
+    if (fast) {                                             // GLABC_MATH_FAST: teams of two or three wavefronts
+        switch (nw) {
+        case 2: return launch_team<D, YD, N, 2, true>(a, prio, s);
+        case 3: return launch_team<D, YD, N, 3, true>(a, prio, s);
+        default: return GLABC_ERR_ARG;
+        }
+    }
     switch (nw) {
-    case 2: return launch_team<D, YD, N, 2>(a, prio, s);
-    case 3: return launch_team<D, YD, N, 3>(a, prio, s);
-    case 4: return launch_team<D, YD, N, 4>(a, prio, s);
+    case 2: return launch_team<D, YD, N, 2, false>(a, prio, s);
+    case 3: return launch_team<D, YD, N, 3, false>(a, prio, s);
+    case 4: return launch_team<D, YD, N, 4, false>(a, prio, s);
     default: return GLABC_ERR_ARG;
     }
 }
 
 template <>
-int launch_team_dim<GLABC_DIM, GLABC_YDIM>(int n_batch, int nw, const StepArgs<GLABC_DIM, GLABC_YDIM>& a, int prio, hipStream_t s)
+int launch_team_dim<GLABC_DIM, GLABC_YDIM>(int n_batch, int nw, const StepArgs<GLABC_DIM, GLABC_YDIM>& a, int prio, bool fast, hipStream_t s)
 {
     constexpr int D = GLABC_DIM, YD = GLABC_YDIM;
     switch (n_batch) {
-#define GLABC_CASE(n) case n: return launch_team_nw<D, YD, n>(nw, a, prio, s);
+#define GLABC_CASE(n) case n: return launch_team_nw<D, YD, n>(nw, a, prio, fast, s);
         GLABC_CASE(2) GLABC_CASE(3) GLABC_CASE(4) GLABC_CASE(5) GLABC_CASE(6) GLABC_CASE(7) GLABC_CASE(8)
         GLABC_CASE(9) GLABC_CASE(10) GLABC_CASE(11) GLABC_CASE(12) GLABC_CASE(13) GLABC_CASE(14) GLABC_CASE(15) GLABC_CASE(16)
 #undef GLABC_CASE

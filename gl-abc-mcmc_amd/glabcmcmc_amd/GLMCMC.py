@@ -28,12 +28,14 @@ from . import _capi, _host, engine, generic
 def GLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
            filelocation, global_frequency=0, Importance_Proposal=None, batch_size=None, *,
            seed=None, device=None, chain0=0, record_history=True, stats=None, return_device=False,
-           steps_per_launch=None, verbose=True, state_out=None, path="auto", **generic_kw):
+           steps_per_launch=None, verbose=True, state_out=None, path="auto", fast_math=False, **generic_kw):
     if Importance_Proposal is None or batch_size is None:
         raise ValueError("GLMCMC needs Importance_Proposal and batch_size (GLMCMC.py:54,66)")
     if path not in ("auto", "fused", "generic"):
         raise ValueError("path must be 'auto', 'fused' or 'generic'")
-    if path == "generic" or (path == "auto" and not generic.fused_supported(ABCset, (Local_Proposal, Importance_Proposal),
+    if fast_math and path == "generic":
+        raise ValueError("fast_math is a variant of the fused kernel (glabc_run.math_mode = GLABC_MATH_FAST)")
+    if path == "generic" or (path == "auto" and not fast_math and not generic.fused_supported(ABCset, (Local_Proposal, Importance_Proposal),
                                                                              batch_size, _capi.MAX_BATCH_WIDE, gamma_ok=True)):
         return generic.run(_capi.ALGO_GLMCMC, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Importance_Proposal,
                            filelocation, global_frequency, batch_size, "glmcmc", seed=seed, device=device, chain0=chain0,
@@ -53,7 +55,8 @@ def GLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
         engine.init_weights(model, imp, chains)                    # GLMCMC.py:52-55
     engine.run_steps("glabc_glmcmc_steps", model, local, imp, chains, num_ite - 1, 1, engine.draw_seed(seed),
                      global_frequency, batch_size, history=None if hist is None else hist[1:], moments=stats,
-                     steps_per_launch=steps_per_launch, rtc_program=rtc)
+                     steps_per_launch=steps_per_launch, rtc_program=rtc,
+                     math_mode=_capi.MATH_FAST if fast_math else _capi.MATH_EXACT)
     if state_out is not None:
         state_out["chains"] = chains
     return _host.finish(hist, chains, single, filelocation, "glmcmc", verbose and single, return_device)

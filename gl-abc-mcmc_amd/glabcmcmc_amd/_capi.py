@@ -28,6 +28,7 @@ FLAG_LOCAL = 1
 DEBUG_EXACT_INDEX = 1          # glabc_run.debug_flags
 DEBUG_NO_TEAM = 2              # glabc_glmcmc_steps: never / always the two-wavefront team geometry (csrc/glabc_team.h)
 DEBUG_TEAM = 4
+DEBUG_DEFAULT_SCHEDULE = 8     # one lane per chain: the default-schedule objects also for small launches
 FLAG_TH64 = 2
 FLAG_LW64 = 4
 FLAG_HAS_GRAD = 8
@@ -204,6 +205,14 @@ ALGO_GLMALA = 2
 SLOT_REDRAW = 0x40000000
 
 
+class DrawsOut(C.Structure):
+    """struct glabc_draws_out"""
+    _fields_ = [("u", C.c_void_p), ("r", C.c_void_p), ("z", C.c_void_p)]
+
+
+MATH_EXACT, MATH_FAST = 0, 1       # glabc_run.math_mode
+
+
 class Run(C.Structure):
     """struct glabc_run"""
     _fields_ = [
@@ -220,6 +229,9 @@ class Run(C.Structure):
         ("debug_flags", C.c_int32),
         ("step0_device", C.c_void_p),
         ("global_frequency_per_chain", C.c_void_p),
+        ("math_mode", C.c_int32),
+        ("reserved", C.c_int32),
+        ("dump_draws", C.POINTER(DrawsOut)),
     ]
 
 
@@ -292,6 +304,20 @@ class HipLibraryMissing(RuntimeError):
     pass
 
 
+def bind(path):
+    """ctypes handle of a build of the C-ABI library with every entry point's signature set; refuses another ABI version"""
+    handle = C.CDLL(path)
+    for name, (res, args) in ENTRY_POINTS.items():
+        fn = getattr(handle, name)     # AttributeError here = ABI mismatch, deliberately loud
+        fn.restype = res
+        fn.argtypes = args
+    got = handle.glabc_version()
+    if got != VERSION:                 # a stale library would misread the argument structs (include/glabc.h GLABC_VERSION)
+        raise HipLibraryMissing("%s is version %d, this binding is for %d: rebuild it (python __graft_entry__.py build)"
+                                % (path, got, VERSION))
+    return handle
+
+
 def lib():
     """The loaded C-ABI library; raises HipLibraryMissing if it has not been built."""
     global _lib
@@ -300,16 +326,7 @@ def lib():
             raise HipLibraryMissing(
                 "%s not found: build it with `python __graft_entry__.py build` "
                 "(hipcc --offload-arch=gfx950). The sampler hot path has no CPU fallback." % LIB_PATH)
-        handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in ENTRY_POINTS.items():
-            fn = getattr(handle, name)     # AttributeError here = ABI mismatch, deliberately loud
-            fn.restype = res
-            fn.argtypes = args
-        got = handle.glabc_version()
-        if got != VERSION:                 # a stale library would misread the argument structs (include/glabc.h GLABC_VERSION)
-            raise HipLibraryMissing("%s is version %d, this binding is for %d: rebuild it (python __graft_entry__.py build)"
-                                    % (LIB_PATH, got, VERSION))
-        _lib = handle
+        _lib = bind(LIB_PATH)
     return _lib
 
 

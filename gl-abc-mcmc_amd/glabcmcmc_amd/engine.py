@@ -133,7 +133,7 @@ class Moments:
 
 def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0, seed, global_frequency, batch_size,
               history=None, moments=None, steps_per_launch=None, lanes_per_chain=0, debug_flags=0, gf_per_chain=None,
-              rtc_program=None):
+              rtc_program=None, math_mode=0, dump_draws=None):
     """Advance `chains` by n_steps iterations with the C-ABI entry point `entry`
     ('glabc_glmcmc_steps' / 'glabc_globalmcmc_steps'), K iterations per launch.
 
@@ -143,6 +143,10 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
     gf_per_chain: None or float32 device tensor [C] replacing global_frequency chain by chain.
     rtc_program: handle of glabc_rtc_compile -- the launches then go to glabc_rtc_steps (a Model whose simulator was compiled
     into the kernel at run time, compiled.CompiledModel) with the same arguments.
+    math_mode: _capi.MATH_EXACT (default: the specified arithmetic, reproduced bit for bit by the CPU checker) or _capi.MATH_FAST
+    (glabc_glmcmc_steps only, opt-in: hardware transcendentals -- the same law from another stream of normals, include/glabc.h).
+    dump_draws: MATH_FAST only -- (u [C][n_steps][2] float32, r [C][n_steps] float64, z [C][n_steps][N][d + y_dim] float32) device
+    tensors that receive the draws the kernel used, in the layout of glabc_tape (one launch: steps_per_launch >= n_steps).
     """
     lib = _capi.lib()
     if rtc_program is not None:
@@ -168,6 +172,12 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
             run.batch_size = int(batch_size or 1)
             run.lanes_per_chain = int(lanes_per_chain)
             run.debug_flags = int(debug_flags)
+            run.math_mode = int(math_mode)
+            if dump_draws is not None:
+                if k != n_steps:
+                    raise ValueError("dump_draws covers one launch: steps_per_launch must be >= n_steps")
+                do = _capi.DrawsOut(dump_draws[0].data_ptr(), dump_draws[1].data_ptr(), dump_draws[2].data_ptr())
+                run.dump_draws = C.pointer(do)
             if gf_per_chain is not None:
                 run.global_frequency_per_chain = gf_per_chain.data_ptr()
             if history is not None:

@@ -192,7 +192,31 @@ typedef struct glabc_run {
     const float* global_frequency_per_chain;   /* NULL, or device array [n_chains] that replaces global_frequency chain by
                                       chain -- a hyper-parameter grid (examples/Mixture_hyper.py:24) is then one launch.
                                       glabc_glmcmc_steps / glabc_globalmcmc_steps only */
+    int32_t math_mode;             /* GLABC_MATH_EXACT (0, default) or GLABC_MATH_FAST, see below */
+    int32_t reserved;
+    const struct glabc_draws_out* dump_draws;  /* GLABC_MATH_FAST only: NULL, or where the kernel WRITES the draws it used */
 } glabc_run;
+
+/* glabc_run.math_mode -- an OPT-IN variant of glabc_glmcmc_steps (batch size 2..GLABC_MAX_BATCH, theta_dim <= 4, the
+ * |theta| + noise simulator; anything else returns GLABC_ERR_ARG).
+ *   GLABC_MATH_EXACT  every elementary function is the specified sequence of IEEE operations of include/glabc_numerics.h: the
+ *                     CPU checker reproduces every bit.  The default, and what every parity statement in this repository is about.
+ *   GLABC_MATH_FAST   Box-Muller with the hardware's v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32, the iSIR weights with
+ *                     v_exp_f32, the accept uniform's logarithm with v_log_f32, the discrepancy's square root with v_sqrt_f32 and
+ *                     the division by the kernel width with v_rcp_f32 (about 1 ulp each).  The normals are then NOT the checker's:
+ *                     the run samples the same law from another stream.  Parity is shown the teacher-forced way (SURVEY.md
+ *                     appendix A.4): with dump_draws set the kernel records every uniform and normal it used in the glabc_tape
+ *                     layout; the CPU checker replays that tape through the EXACT arithmetic and must take the same accept /
+ *                     resample decisions except where a decision lies within rounding of its threshold
+ *                     (tests/test_hip_parity.py::test_fast_math_*).  Philox, the candidates' arithmetic (IEEE + - x), torch.sum's
+ *                     order and the double-precision index are unchanged. */
+#define GLABC_MATH_EXACT 0
+#define GLABC_MATH_FAST 1
+typedef struct glabc_draws_out {   /* device arrays covering exactly the call's n_steps, layout of glabc_tape */
+    float* u;                      /* [n_chains][n_steps][2] */
+    double* r;                     /* [n_chains][n_steps] */
+    float* z;                      /* [n_chains][n_steps][batch_size][theta_dim + y_dim] */
+} glabc_draws_out;
 
 /* glabc_run.debug_flags: the iSIR index (GLMCMC.py:7-22) is normally found from float32 reciprocal-multiplied
  * weights and recomputed the reference's way (IEEE divisions, double partial sums) only when the resampling uniform
@@ -204,6 +228,10 @@ typedef struct glabc_run {
  * iteration ahead).  These bits forbid / force that geometry -- tests use them to show that both give the same chains. */
 #define GLABC_DEBUG_NO_TEAM 2
 #define GLABC_DEBUG_TEAM 4
+/* One lane per chain, launches of at most two wavefronts per SIMD: the library picks the build of the kernels scheduled for
+ * instruction-level parallelism; this bit picks the default-schedule build (the one larger launches get) -- so that a test
+ * can walk EVERY instantiation with small launches (tests/test_slp_twin.py). */
+#define GLABC_DEBUG_DEFAULT_SCHEDULE 8
 
 /* ---- entry points ------------------------------------------------------------ */
 

@@ -1165,3 +1165,191 @@ def test_gamma_descriptor_entry_points(hip, oracle):
     bad.p0[1] = -1.0
     assert hip.glabc_glmcmc_steps(C.byref(model), C.byref(local), C.byref(bad), C.byref(cs), C.byref(run), None) == -4
     torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------- BASELINE configs[0], literally
+def test_config_1_runner_global_mcmc_one_chain_10000_iterations(hip, oracle, tmp_path, capsys):
+    """BASELINE.json configs[0]: Mixture_set eps 0.05, dim 2, ONE chain x 10 000 iterations through MCMCRunner.run_global_mcmc
+    with the CSV side effect, on the GPU.  The returned Theta_Re is the reference's shape and dtype ((num_ite, 2) float32 on
+    the CPU, row 0 = theta_0), equals the CPU checker's chain bit for bit, and the file is what the reference's dump schedule
+    (GlobalMCMC.py:70-76: header = theta_0, a block at i % 10000 == 0 and at the last iteration -- here no duplicated tail,
+    num_ite - 1 = 9 999) writes for that chain: csv.writer rows of numpy float32 values."""
+    import csv as csvmod
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import _host
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    num_ite, seed, gf = 10_000, 20261004, 0.5
+    m = Mixture_set(0.05)
+    lp = g_.DiagGaussian(2, loc=torch.zeros(1, 2), log_scale=torch.log(torch.tensor([0.35, 0.35])))
+    gp = g_.DiagGaussian(2, torch.tensor([0.0, 0.0]), torch.tensor([0.0, 0.0]))
+    theta0 = torch.tensor([0.0, 0.0])
+    y0 = torch.tensor([[0.21, -0.13]])
+    runner = g_.MCMCRunner(m, output_dir=str(tmp_path / "out"))
+    out = runner.run_global_mcmc(num_ite, theta0, y0, gf, lp, gp, output_file="global_mcmc_results.csv", seed=seed)
+    assert out.shape == (num_ite, 2) and out.dtype == torch.float32 and out.device.type == "cpu"
+    assert torch.equal(out[0], theta0)
+    assert capsys.readouterr().out.strip() != ""                              # the end-of-run summary print (GlobalMCMC.py:92-96)
+    # the checker's chain
+    model, local, glob = m.descriptor(), lp.descriptor(), gp.descriptor()
+    hh, hc, _ = oracle_run(oracle, "globalmcmc", model, local, glob, theta0.view(1, 2).numpy(), y0.numpy(), num_ite - 1, seed, gf, 1)
+    want = np.concatenate([theta0.view(1, 2).numpy(), hh[:, :, 0]], axis=0)
+    assert np.array_equal(bits(out.numpy()), bits(want))
+    moves = int((np.diff(want, axis=0) != 0).any(1).sum())
+    assert 30 < moves < 2000, moves                                           # eps 0.05: about one move in a hundred iterations
+    # the CSV: the file the run wrote == the reference schedule applied to the chain
+    path = tmp_path / "out" / "global_mcmc_results.csv"
+    rows = list(csvmod.reader(open(path)))
+    assert len(rows) == num_ite                                               # header (theta_0) + rows 1 .. 9999, no duplicated block
+    got = np.array(rows, dtype=np.float32)
+    assert np.array_equal(bits(got), bits(want))
+    ref_file = tmp_path / "ref.csv"
+    _host.write_csv(torch.from_numpy(want), str(ref_file), "global")
+    assert open(path, "rb").read() == open(ref_file, "rb").read()
+
+
+# ---------------------------------------------------------------------------------- GLABC_MATH_FAST (opt-in), teacher-forced parity
+def _fast_run(model, local, glob, theta0, y0, T, seed, gf, N, chain0=0, dump=True, moments=False):
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import engine
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0)
+    engine.init_weights(model, glob, chains)
+    n, d, yd = chains.n, chains.d, chains.yd
+    hist = torch.empty(T, d, n, dtype=torch.float32, device=dev)
+    tape = None
+    if dump:
+        tape = (torch.zeros(n, T, 2, dtype=torch.float32, device=dev), torch.zeros(n, T, dtype=torch.float64, device=dev),
+                torch.zeros(n, T, N, d + yd, dtype=torch.float32, device=dev))
+    mom = engine.Moments(n, d, dev) if moments else None
+    engine.run_steps("glabc_glmcmc_steps", model, local, glob, chains, T, 1, seed, gf, N, history=hist, moments=mom,
+                     math_mode=A.MATH_FAST, dump_draws=tape)
+    torch.cuda.synchronize()
+    return hist.cpu().numpy(), chains, mom, None if tape is None else tuple(t.cpu().numpy() for t in tape)
+
+
+FAST_CASES = [
+    # d, N, gf, eps, local, global
+    (2, 5, 0.9, 0.05, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1])),                # the bench configuration
+    (2, 8, 0.6, 0.3, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0.1, -0.1], [1.0, 1.25])),       # VAR_GENERIC
+    (3, 4, 0.7, 0.3, ("uniform", [-0.4] * 3, [0.4] * 3), ("uniform", [-3] * 3, [3] * 3)),
+    (1, 16, 0.8, 0.2, ("gauss", [0], [0.4]), ("gauss", [0], [1])),
+]
+
+
+@pytest.mark.parametrize("case", FAST_CASES, ids=lambda c: "d%d-N%d-%s" % (c[0], c[1], c[5][0]))
+def test_fast_math_decisions_follow_the_checker_on_the_kernels_own_draws(hip, oracle, case):
+    """glabc_run.math_mode = GLABC_MATH_FAST (opt-in, include/glabc.h), parity the teacher-forced way: the
+    kernel records every uniform and normal it drew; the CPU checker replays that tape through the EXACT arithmetic.  Candidates
+    are IEEE functions of the draws, so a chain's states are bit-identical as long as the decisions agree; a chain may leave the
+    checker's path only at a decision that lies within rounding of its threshold -- shown by replaying that chain with the
+    step's resampling uniform moved by 1e-5 or its accept uniform scaled by exp(+-2e-3) and finding the kernel's state.  Such
+    chains must be rare."""
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import distribution
+    d, N, gf, eps, lspec, gspec = case
+    if d == 2:
+        model, local, glob = descriptors(dict(epsilon=eps, local=lspec, **{"global": gspec}))
+    else:
+        prior = distribution.DiagGaussian(d, torch.zeros(d), torch.zeros(d)).descriptor()
+        noise = distribution.DiagGaussian(d, torch.zeros(d), torch.log(torch.full((d,), 0.05).sqrt())).descriptor()
+        kern = distribution.DiagGaussian(1, torch.tensor([0.0]), torch.log(torch.tensor([eps]))).descriptor()
+        model = A.Model()
+        model.sim_kind, model.theta_dim, model.y_dim = A.SIM_ABS_GAUSS, d, d
+        model.prior, model.noise = prior, noise
+        for j in range(d):
+            model.y_obs[j] = 1.5 - 0.25 * j
+        model.kern_log_scale, model.kern_scale, model.kern_c0, model.epsilon = kern.p1[0], kern.p2[0], kern.c0, eps
+        local, glob = make_dist(lspec).descriptor(), make_dist(gspec).descriptor()
+    n, T, seed = 4096, 40, 20261004
+    rng = np.random.default_rng(7 * N + d)
+    theta0 = rng.standard_normal((n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
+    hist, chains, _, (tu, tr, tz) = _fast_run(model, local, glob, theta0, y0, T, seed, gf, N, chain0=77)
+    assert np.isfinite(tz).all() and abs(tz.mean()) < 0.05 if gspec[0] == "gauss" else True
+
+    def replay(idx, u, r, z):
+        """the checker on the tape rows of chains idx -> history (T, d, len(idx))"""
+        hc = oracle_lib.HostChains(theta0[idx], y0[idx], chain0=77)
+        hh = np.zeros((T, d, len(idx)), np.float32)
+        run, keep = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh,
+                                        tape=(np.ascontiguousarray(u), np.ascontiguousarray(r), np.ascontiguousarray(z), N))
+        cs = hc.struct()
+        assert oracle.oracle_init_weights(C.byref(model), C.byref(glob), C.byref(cs)) == 0
+        assert oracle.oracle_glmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run)) == 0
+        return hh
+
+    hh = replay(np.arange(n), tu, tr, tz)
+    differ = (bits(hist) != bits(hh)).any(axis=(0, 1))
+    moved = (np.diff(hist, axis=0) != 0).any(axis=1).sum()
+    assert moved > n                                                             # the run does something
+    flipped = np.flatnonzero(differ)
+    assert len(flipped) <= max(4, n // 200), "%d of %d chains leave the checker's path" % (len(flipped), n)
+    unexplained = []
+    for c in flipped:
+        t0 = int(np.flatnonzero((bits(hist[:, :, c]) != bits(hh[:, :, c])).any(axis=1))[0])
+        ok = False
+        for dr, fu in ((1e-5, 1.0), (-1e-5, 1.0), (0.0, float(np.exp(2e-3))), (0.0, float(np.exp(-2e-3)))):
+            u2, r2 = tu[c:c + 1].copy(), tr[c:c + 1].copy()
+            r2[0, t0] = min(max(r2[0, t0] + dr, 0.0), 1.0 - 2 ** -53)
+            u2[0, t0, 1] = np.float32(min(u2[0, t0, 1] * fu, 1.0 - 2 ** -24))
+            h2 = replay(np.array([c]), u2, r2, tz[c:c + 1])
+            ok = ok or np.array_equal(bits(h2[t0, :, 0]), bits(hist[t0, :, c]))
+        if not ok:
+            unexplained.append((int(c), t0))
+    assert not unexplained, "decisions that differ beyond rounding of their threshold: %s" % unexplained[:5]
+    print("fast math d=%d N=%d: %d of %d chains take a within-rounding decision the other way in %d iterations"
+          % (d, N, len(flipped), n, T))
+
+
+def test_fast_math_samples_the_same_law(hip):
+    """65 536 chains x 1000 iterations of the bench configuration, exact and fast kernel: E theta^2 (analytic 2.081014), E|theta|
+    and ESJD agree within 1e-3 relative plus four combined standard errors (north_star's tolerance for posterior moments / ESJD)"""
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import engine
+    model, local, glob = descriptors(dict(epsilon=0.05, local=("gauss", [0, 0], [0.35, 0.35]), **{"global": ("gauss", [0, 0], [1, 1])}))
+    n, burn, T = 65536, 300, 1000
+    dev = torch.device("cuda", 0)
+    stats = {}
+    for mode in (A.MATH_EXACT, A.MATH_FAST):
+        g = torch.Generator().manual_seed(5)
+        chains = engine.ChainBatch(torch.zeros(n, 2), (0.05 ** 0.5) * torch.randn(n, 2, generator=g), dev)
+        engine.init_weights(model, glob, chains)
+        engine.run_steps("glabc_glmcmc_steps", model, local, glob, chains, burn, 1, 99, 0.9, 5, math_mode=mode)
+        mom = engine.Moments(n, 2, dev)
+        hist = torch.empty(T, 2, n, dtype=torch.float32, device=dev)
+        engine.run_steps("glabc_glmcmc_steps", model, local, glob, chains, T, 1 + burn, 99, 0.9, 5, moments=mom, history=hist,
+                         math_mode=mode)
+        torch.cuda.synchronize()
+        sq = (mom.sum_outer[0] / T).cpu().numpy()
+        ab = hist[:, 0, :].abs().double().mean(0).cpu().numpy()
+        es = mom.esjd().double().cpu().numpy()
+        es = es[np.isfinite(es)]                          # a chain whose jump matrix is singular in float32 has no ESJD (bench.py: esjd_nan_frac)
+        assert len(es) > 0.99 * n
+        stats[mode] = {k: (v.mean(), v.std(ddof=1) / np.sqrt(len(v))) for k, v in (("sq", sq), ("abs", ab), ("esjd", es))}
+    for k in ("sq", "abs", "esjd"):
+        (a, sa), (b, sb) = stats[A.MATH_EXACT][k], stats[A.MATH_FAST][k]
+        assert abs(a - b) <= 1e-3 * abs(a) + 4 * np.hypot(sa, sb), (k, a, b, sa, sb)
+    assert abs(stats[A.MATH_FAST]["sq"][0] - 2.081014) < 1e-3 * 2.081014 + 4 * stats[A.MATH_FAST]["sq"][1]
+
+
+def test_fast_math_is_refused_where_it_does_not_exist(hip):
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import engine
+    model, local, glob = descriptors(dict(epsilon=0.3, local=("gauss", [0, 0], [0.3, 0.3]), **{"global": ("gauss", [0, 0], [1, 1])}))
+    dev = torch.device("cuda", 0)
+    chains = engine.ChainBatch(torch.zeros(8, 2), torch.ones(8, 2), dev).add_mala_state()
+    cs = chains.struct()
+
+    def call(fn=hip.glabc_glmcmc_steps, **kw):
+        run = A.Run()
+        run.seed, run.step0, run.n_steps, run.global_frequency, run.batch_size, run.math_mode = 1, 1, 2, 0.5, 5, A.MATH_FAST
+        for k, v in kw.items():
+            setattr(run, k, v)
+        return fn(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run), None)
+
+    assert call() == 0
+    assert call(batch_size=1) == -4 and call(batch_size=17) == -4 and call(lanes_per_chain=2) == -4 and call(math_mode=2) == -4
+    assert call(fn=hip.glabc_globalmcmc_steps) == -4
+    do = A.DrawsOut(None, None, None)
+    assert call(dump_draws=C.pointer(do)) == -1 and call(math_mode=A.MATH_EXACT, dump_draws=C.pointer(do)) == -4
+    torch.cuda.synchronize()

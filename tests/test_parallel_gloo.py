@@ -109,3 +109,35 @@ def test_row_weighted_gradient_average_and_refresh_vote():
     for r in res:
         assert torch.allclose(r[1], torch.full((4, 5), want_g)) and abs(float(r[2][0]) - want_b0) < 1e-5
         assert abs(float(r[2][1]) + 1.0) < 1e-6 and abs(float(r[3]) - want_loss) < 1e-6 and r[4] == 9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,chains", [("glmcmc", 16384), ("gk", 8192)])
+def test_bench_rehearsal_four_ranks_on_one_gpu_equals_one_rank(workload, chains):
+    """The driver's multi-GPU run, rehearsed: `bench.py --gpus 4 --rehearse-gloo` -- four processes launched exactly as the
+    driver launches them (torch.distributed.run, one rank per process), all on the one leased GPU, collectives on gloo -- against
+    ONE rank that runs the same 4 x `chains` chains.  Chains are sharded by global chain id and the synthetic inputs are a
+    function of it, so the pooled statistics (ESJD, moments) must be identical to the last bit; what the driver's 8-GPU run
+    adds is only the backend string ('nccl') and one GPU per rank.  (Four ranks, not eight: the GPU box allows six processes on
+    its card.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", workload, "--steps", "2", "--warmup", "1", "--iters", "150", "--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--chains", str(4 * chains)] + common,
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    four = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                           "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "4", "--rehearse-gloo",
+                           "--chains", str(chains)] + common, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert four.returncode == 0, four.stderr[-2000:]
+    a = json.loads([l for l in one.stdout.strip().split("\n") if l.startswith("{")][-1])
+    b = json.loads([l for l in four.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert (a["n_gpus"], b["n_gpus"]) == (1, 4) and b["scaling"] == "weak"
+    assert a["config"]["chains_per_gpu"] == 4 * b["config"]["chains_per_gpu"]
+    for key in ("esjd_mean", "mean_theta", "mean_theta_sq", "moment_iters", "esjd_nan_frac"):
+        assert a[key] == b[key], (key, a[key], b[key])
+    assert a["esjd_mean"] > 0
