@@ -136,6 +136,103 @@ __device__ __forceinline__ void coupling_params2(const float* __restrict__ lds, 
     log_s_b = ((half ? qb1 : pb1) + (half ? pb1 : qb1)) + b31;
 }
 
+// The same arithmetic with the OUTPUT TILE outermost (the default since round 3; 103.4 -> 108.6 TFLOP/s): tile t's 128 MFMAs (k ascending, two rows' tiles
+// a / b per A operand) run while the W3 reduction of tile t-1 -- whose accumulators are complete -- is spread over them, one
+// hidden unit every fourth k step.  Only the last tile's reduction is exposed (a quarter of the epilogue), and two tiles of
+// accumulators are alive instead of four (64 registers instead of 128).  h1 is made four times (once per tile): 2 VALU per
+// MFMA pair, in the shadow of the matrix pipe.  Same bits: every accumulator is the same k-ordered chain, the W3 partial
+// sums visit the hidden units in the same tile-then-register order.
+template <int T>
+__device__ __forceinline__ void nf_tile_pass(const float* __restrict__ lds, float z0a, float z0b, int half, int col, f32x16& xa,
+                                             f32x16& xb, const f32x16& ya, const f32x16& yb, float& pa0, float& pa1, float& pb0,
+                                             float& pb1)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = 32 * T + (r & 3) + 8 * (r >> 2) + 4 * half;
+        xa[r] = xb[r] = lds[L_V4 + 4 * i];
+    }
+    const float* w1 = lds + L_W1 + half;
+    const float* bb1 = lds + L_B1 + half;
+    const float* wt = lds + L_W2 + half * NF_H + col + 32 * T;
+    // groups of four k steps (8 MFMAs = 512 cycles of the matrix pipe); the operands of group g + 1 are fetched from LDS at the top
+    // of group g, and a scheduling barrier per group keeps the compiler from hoisting all 192 loads of a tile to its head
+    float w[4], bi[4], wv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        w[q] = w1[2 * q];
+        bi[q] = bb1[2 * q];
+        wv[q] = wt[2 * q * NF_H];
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        float nw[4], nbi[4], nwv[4];
+        if (g < 15) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sn = 4 * (g + 1) + q;
+                nw[q] = w1[2 * sn];
+                nbi[q] = bb1[2 * sn];
+                nwv[q] = wt[2 * sn * NF_H];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float ha = __builtin_fmaxf(__builtin_fmaf(w[q], z0a, bi[q]), 0.0f);
+            const float hb = __builtin_fmaxf(__builtin_fmaf(w[q], z0b, bi[q]), 0.0f);
+            xa = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q], ha, xa, 0, 0, 0);
+            xb = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[q], hb, xb, 0, 0, 0);
+        }
+        if constexpr (T > 0) {                                         // hidden unit g of the PREVIOUS tile, in register order
+            const int i = 32 * (T - 1) + (g & 3) + 8 * (g >> 2) + 4 * half;
+            const float2 v = *reinterpret_cast<const float2*>(lds + L_V4 + 4 * i + 1);
+            const float qa = __builtin_fmaxf(ya[g], 0.0f), qb = __builtin_fmaxf(yb[g], 0.0f);
+            pa0 = __builtin_fmaf(v.x, qa, pa0);
+            pa1 = __builtin_fmaf(v.y, qa, pa1);
+            pb0 = __builtin_fmaf(v.x, qb, pb0);
+            pb1 = __builtin_fmaf(v.y, qb, pb1);
+        }
+        if (g < 15) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                w[q] = nw[q];
+                bi[q] = nbi[q];
+                wv[q] = nwv[q];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void coupling_params2_tile_outer(const float* __restrict__ lds, float z0a, float z0b, int lane, float& shift_a,
+                                                            float& log_s_a, float& shift_b, float& log_s_b)
+{
+    const int half = lane >> 5, col = lane & 31;
+    f32x16 a0, b0, a1, b1, a2, b2, a3, b3;
+    float pa0 = 0.0f, pa1 = 0.0f, pb0 = 0.0f, pb1 = 0.0f;
+    nf_tile_pass<0>(lds, z0a, z0b, half, col, a0, b0, a0, b0, pa0, pa1, pb0, pb1);
+    nf_tile_pass<1>(lds, z0a, z0b, half, col, a1, b1, a0, b0, pa0, pa1, pb0, pb1);
+    nf_tile_pass<2>(lds, z0a, z0b, half, col, a2, b2, a1, b1, pa0, pa1, pb0, pb1);
+    nf_tile_pass<3>(lds, z0a, z0b, half, col, a3, b3, a2, b2, pa0, pa1, pb0, pb1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                     // the last tile's reduction
+        const int i = 96 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float2 v = *reinterpret_cast<const float2*>(lds + L_V4 + 4 * i + 1);
+        const float qa = __builtin_fmaxf(a3[r], 0.0f), qb = __builtin_fmaxf(b3[r], 0.0f);
+        pa0 = __builtin_fmaf(v.x, qa, pa0);
+        pa1 = __builtin_fmaf(v.y, qa, pa1);
+        pb0 = __builtin_fmaf(v.x, qb, pb0);
+        pb1 = __builtin_fmaf(v.y, qb, pb1);
+    }
+    const float qa0 = __shfl_xor(pa0, 32, 64), qa1 = __shfl_xor(pa1, 32, 64);
+    const float qb0 = __shfl_xor(pb0, 32, 64), qb1 = __shfl_xor(pb1, 32, 64);
+    const float b30 = lds[L_B3 + 0], b31 = lds[L_B3 + 1];
+    shift_a = ((half ? qa0 : pa0) + (half ? pa0 : qa0)) + b30;
+    log_s_a = ((half ? qa1 : pa1) + (half ? pa1 : qa1)) + b31;
+    shift_b = ((half ? qb0 : pb0) + (half ? pb0 : qb0)) + b30;
+    log_s_b = ((half ? qb1 : pb1) + (half ? pb1 : qb1)) + b31;
+}
+
 // One row tile per wavefront: the form for small inputs (at most one tile per CU), where the launch is a latency chain
 // and half the MFMAs per coupling beat operand reuse.  Same arithmetic per row as coupling_params2.
 __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, float z0, int lane, float& shift, float& log_s)
@@ -263,18 +360,42 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
     const int64_t n_rows = a.n_dev ? (int64_t)*a.n_dev : a.n_rows;     // indexed mode: the row count lives on the device
     if (wg_row0 >= n_rows) return;                                     // (workgroup-uniform, before any barrier)
     const int n_pairs = a.rows_per_wg / 64;                            // pair mode: 64-row pairs in this workgroup
-    float* st = lds + NF_BLOCK_FLOATS + wave * a.state_floats_per_wave;   // [slot][tile a/b][z0, z1, lq][32 rows]
+    float* st = lds + NF_BLOCK_FLOATS;                                 // pair mode: [pair][tile a/b][z0, z1, lq][32 rows]
+    // Pair mode: which pairs are this wavefront's.  The matrix pipe belongs to a SIMD, so the pairs are dealt to the SIMDs first
+    // (pair p -> SIMD p % 4) and only then to the wavefronts that happen to sit on that SIMD (HW_ID), whatever order the
+    // dispatcher placed them in: with 20 pairs on 12 or 16 wavefronts a deal by wavefront index leaves one SIMD with 6 .. 8
+    // pairs and another with 3 .. 4, and the workgroup waits for the fullest.  Falls back to the wavefront index if a SIMD
+    // holds none of the workgroup's wavefronts.
+    int p_first = wave, p_stride = NF_WAVES;
+    if constexpr (!TILE_MODE) {
+        __shared__ int simd_waves[4];
+        if (threadIdx.x < 4) simd_waves[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const int simd = (int)((hw >> 4) & 3u);
+        int rank = 0;
+        if (lane == 0) rank = atomicAdd(&simd_waves[simd], 1);
+        rank = __shfl(rank, 0, 64);
+        __syncthreads();
+        const int n0 = simd_waves[0], n1 = simd_waves[1], n2 = simd_waves[2], n3 = simd_waves[3];
+        if (n0 > 0 && n1 > 0 && n2 > 0 && n3 > 0) {
+            const int mine = simd == 0 ? n0 : simd == 1 ? n1 : simd == 2 ? n2 : n3;
+            p_first = simd + 4 * rank;
+            p_stride = 4 * mine;
+        }
+    }
 
     float z0 = 0.0f, z1 = 0.0f, lq = 0.0f;                             // tile mode only
     const bool tile_active = wave * 32 < a.rows_per_wg;                // wave-uniform
     if constexpr (TILE_MODE) {
         if (tile_active) nf_row_init<INVERSE>(a, n_rows, wg_row0 + (int64_t)wave * 32 + col, z0, z1, lq);
     } else {
-        for (int p = wave, slot = 0; p < n_pairs; p += NF_WAVES, ++slot) {
+        for (int p = p_first; p < n_pairs; p += p_stride) {
             // lane l initialises row 64p + l of the pair: tile a = lanes 0..31, tile b = lanes 32..63
             float i0, i1, il;
             nf_row_init<INVERSE>(a, n_rows, wg_row0 + (int64_t)p * 64 + lane, i0, i1, il);
-            float* s = st + slot * 192 + (lane >> 5) * 96 + col;
+            float* s = st + p * 192 + (lane >> 5) * 96 + col;
             s[0] = i0;
             s[32] = i1;
             s[64] = il;
@@ -303,11 +424,15 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
                 nf_row_apply<INVERSE>(sh, ls, z0, z1, lq);
             }
         } else {
-            for (int p = wave, slot = 0; p < n_pairs; p += NF_WAVES, ++slot) {
-                float* s = st + slot * 192 + col;                      // both lanes of a row read the same words
+            for (int p = p_first; p < n_pairs; p += p_stride) {
+                float* s = st + p * 192 + col;                         // both lanes of a row read the same words
                 float a0 = s[0], a1 = s[32], al = s[64], b0 = s[96], b1 = s[128], bl = s[160];
                 float sa, la, sb, lb;
+#ifdef GLABC_NF_K_OUTER        // the round-2 form (k outermost, all four tiles' accumulators alive): an A/B knob
                 coupling_params2(lds, INVERSE ? a1 : a0, INVERSE ? b1 : b0, lane, sa, la, sb, lb);
+#else
+                coupling_params2_tile_outer(lds, INVERSE ? a1 : a0, INVERSE ? b1 : b0, lane, sa, la, sb, lb);
+#endif
                 if (INVERSE && a.trace) {                              // lane l: row 64 p + l of the pair (tile a | tile b)
                     const int64_t row = wg_row0 + (int64_t)p * 64 + lane;
                     if (row < n_rows) a.trace[(int64_t)c * a.n_rows + row] = lane < 32 ? a1 : b1;
@@ -334,11 +459,11 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
         // being kept alive -- or spilled -- across the coupling loop
         int tid = threadIdx.x;
         __asm__ volatile("" : "+v"(tid));
-        const int lane2 = tid & 63, wave2 = tid >> 6;
-        const float* st2 = lds + NF_BLOCK_FLOATS + wave2 * a.state_floats_per_wave;
-        for (int p = wave2, slot = 0; p < n_pairs; p += NF_WAVES, ++slot) {
+        const int lane2 = tid & 63;
+        const float* st2 = lds + NF_BLOCK_FLOATS;
+        for (int p = p_first; p < n_pairs; p += p_stride) {
             const int64_t row = wg_row0 + (int64_t)p * 64 + lane2;
-            const float* s = st2 + slot * 192 + (lane2 >> 5) * 96 + (lane2 & 31);
+            const float* s = st2 + p * 192 + (lane2 >> 5) * 96 + (lane2 & 31);
             if (row < n_rows) nf_row_store<INVERSE>(a, row, s[0], s[32], s[64]);
         }
     }

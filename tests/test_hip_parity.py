@@ -883,9 +883,10 @@ def test_glmala_law_matches_a_large_reference_sample(hip):
     """north_star: 'posterior moments and ESJD within 1e-3' for GLMALA, whose chains cannot be compared bit for bit with the
     reference as it runs.  tests/golden/glmala_stats.npz holds time averages over 500 iterations of a large
     sample of chains of the UNMODIFIED reference GLMALA run AS IS (tests/golden/make_glmala_stats.py: BASELINE config 3,
-    theta0 = 0); the kernel runs the same experiment on 262 144 chains.  Every pooled statistic must agree within 4 combined
-    standard errors; with the reference's 150 016 chains the combined standard error of the posterior moments (E|theta_j|,
-    E theta_j^2) is below north_star's 1e-3 relative (3e-4 and 6e-4), that of ESJD is 1.7e-3."""
+    theta0 = 0; the fixture records how many -- about 25 CPU-minutes per thousand chains in the build container); the kernel
+    runs the same experiment on 2 097 152 chains.  Every pooled statistic must agree within 4 combined standard errors; the
+    combined standard error of the posterior moments (E|theta_j|, E theta_j^2) must be below north_star's 1e-3 relative, and --
+    once the reference sample has reached 440 000 chains -- that of ESJD and of the move rate as well."""
     from glabcmcmc_amd import GLMALA, distribution, engine
     from glabcmcmc_amd.examples.Mixture import Mixture_set
     g = load_golden("glmala_stats")
@@ -893,7 +894,7 @@ def test_glmala_law_matches_a_large_reference_sample(hip):
     names = eval(str(g["names"]), {"__builtins__": {}}, {})
     ref_mean, ref_se = dict(zip(names, g["mean"])), dict(zip(names, g["se"]))
     assert int(g["n_chains"]) >= 150000
-    n, T = 262144, cfg["T"]
+    n, T = 2097152, cfg["T"]
     dev = torch.device("cuda", 0)
     gen = torch.Generator().manual_seed(99)
     theta0 = torch.zeros(n, 2)
@@ -924,7 +925,12 @@ def test_glmala_law_matches_a_large_reference_sample(hip):
     for k in ("mean_abs_0", "mean_abs_1", "mean_sq_0", "mean_sq_1"):
         m, r, comb = report[k]
         assert comb / abs(r) < 1e-3 and abs(m - r) / abs(r) < 2.5e-3, (k, report[k])
-    assert report["esjd"][2] / report["esjd"][1] < 2e-3
+    tight = int(g["n_chains"]) >= 440000
+    for k in ("esjd", "move_rate"):
+        m, r, comb = report[k]
+        assert comb / abs(r) < (1e-3 if tight else 2e-3), (k, report[k], int(g["n_chains"]))
+        if tight:
+            assert abs(m - r) / abs(r) < 3.5e-3, (k, report[k])
 
 
 # ---------------------------------------------------------------------------------- wide batches (glabc_wide.hip)
