@@ -715,8 +715,12 @@ def run_glmala(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad, fileloc
     glabc_select as in GLMCMC; the MALA local move (GLMALA.py:182-200) -- gradient, drift, reverse density -- is evaluated in
     float64 torch operations on the chains that take it, and its accept / state update / Theta_Re row again by glabc_select.
     Reference behaviours kept: log_weight_old is not refreshed after MALA moves, the cached gradient is not
-    refreshed after iSIR moves, the prior gradient is a float32 finite difference (B3).  The chain state itself stays
-    float32 (the reference's turns float64 after the first accepted MALA move; Theta_Re is float32 there too)."""
+    refreshed after iSIR moves, the prior gradient is a float32 finite difference (B3), and Theta_old becomes a float64 tensor
+    at a chain's first ACCEPTED MALA move and stays one (GLMALA.py:43,197-198: the drift is float64): `theta64` holds the
+    state in double (float32-exact values until the chain's `th64` bit is set), the next proposal and the reverse density
+    start from it -- `z*tau + Theta_old` is a float32 addition before the switch and a float64 one after, as in the fused
+    kernel (GLABC_FLAG_TH64).  Theta_Re is float32 in either case (GLMALA.py:148,200).  y_old is not kept in double: it enters
+    only through calculate_log_kernel(y_old), which is carried from the iteration that proposed it."""
     lib = _capi.lib()
     dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
     n, d, yd = chains.n, chains.d, chains.yd
@@ -751,6 +755,8 @@ def run_glmala(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad, fileloc
     kern_cur = model.kernel(chains.y.t().contiguous()).clone()
     grad = torch.zeros(n, d, dtype=torch.float64, device=dev)                                    # grad_logABC_Theta_old, :146
     has_grad = torch.zeros(n, dtype=torch.bool, device=dev)
+    theta64 = chains.theta.t().double().contiguous()                                             # Theta_old, (n, d)
+    th64 = torch.zeros(n, dtype=torch.bool, device=dev)                                          # ... is a float64 tensor
     hist = _host.allocate_history(num_ite, chains, record_history)
 
     io = _capi.StepIO()
@@ -789,21 +795,24 @@ def run_glmala(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad, fileloc
             L = int(idx.numel())
             g_new = None
             if L:
-                th_old = chains.theta.t()[idx]                                                   # (L, d) float32
+                th_old = theta64[idx]                                                            # (L, d) float64 (float32-exact before the switch)
+                wide = th64[idx].view(-1, 1)
                 need = ~has_grad[idx]
-                if bool(need.any()):                                                             # :183-184
+                if bool(need.any()):                                                             # :183-184 (theta.float(), :62)
                     sub = idx[need]
-                    grad[sub] = _numerical_gradient(model, th_old[need], int(num_grad), eps_sq, gen,
+                    grad[sub] = _numerical_gradient(model, th_old[need].float(), int(num_grad), eps_sq, gen,
                                                     host_rng.integers(0, 2 ** 32, d))
                     has_grad[sub] = True
                 g_old = grad[idx]
                 z = torch.randn(L, d, generator=gen, device=dev)                                 # Local_proposal_forward, :25-44
-                th_new = z * tau + th_old + g_old * tau ** 2 / 2                                 # float64
+                zt = z * tau                                                                     # float32
+                base = torch.where(wide, zt.double() + th_old, (zt + th_old.float()).double())   # float64 add once Theta_old is float64
+                th_new = base + g_old * tau ** 2 / 2                                             # float64, :43
                 logq_fwd = c_norm - (0.5 * z ** 2).sum(1)
                 g_new = _numerical_gradient(model, th_new, int(num_grad), eps_sq, gen, host_rng.integers(0, 2 ** 32, d))   # :187
                 eps1 = torch.randn(L, nd, generator=gen, device=dev) if nd else None
                 y_new = model.simulate(th_new, eps1)                                             # :188-189
-                e_rev = (th_old.double() - th_new - g_new * tau ** 2 / 2) / tau                  # log_proposal, :97-116
+                e_rev = (th_old - th_new - g_new * tau ** 2 / 2) / tau                           # log_proposal, :97-116
                 rev = c_norm - (0.5 * e_rev ** 2).sum(1)
                 theta_prop[idx] = th_new.float()
                 y_prop[idx] = y_new
@@ -815,13 +824,17 @@ def run_glmala(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad, fileloc
                 q_cur = global_cb.log_prob(chains.theta.t().contiguous())
                 io.q_cur = q_cur.data_ptr()
             _capi.check(lib.glabc_select(_capi.ALGO_GLMALA, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_select")
+            gm = ((is_global & 1) != 0) & ((is_global & 2) != 0)                                 # an accepted iSIR move: a float32 candidate
+            theta64[gm] = chains.theta.t()[gm].double()
             if L:                                                                                # :194-199
                 moved = (is_global[idx] & 2) != 0
                 grad[idx[moved]] = g_new[moved]
+                theta64[idx[moved]] = th_new[moved]                                              # :197 Theta_old = Theta_prop (float64)
+                th64[idx[moved]] = True
             if progress is not None:
                 progress(i)
     if stats is not None:
         stats.steps += num_ite - 1
     if state_out is not None:
-        state_out.update(chains=chains, grad=grad, has_grad=has_grad, callback_device=model.where)
+        state_out.update(chains=chains, grad=grad, has_grad=has_grad, theta64=theta64, th64=th64, callback_device=model.where)
     return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)

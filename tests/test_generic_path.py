@@ -430,6 +430,15 @@ def test_hip_generic_glmala_has_the_law_of_the_fused_kernel(hip, model_kind):
         jump = (mom.sum_jump[0] + mom.sum_jump[2]).cpu().numpy() / T
         moves = st["chains"].n_moves.cpu().numpy().astype(np.float64) / T
         res.append((sq, jump, moves))
+        if which == "generic":
+            # the reference's precision switch (GLMALA.py:43,197-198): Theta_old is a float64 tensor from a chain's first
+            # accepted MALA move on; its float32 cast is the state Theta_Re records
+            th64, wide = st["theta64"], st["th64"]
+            assert th64.dtype == torch.float64 and 0.05 < float(wide.float().mean()) <= 1.0
+            assert torch.equal(th64.float(), st["chains"].theta.t())
+            narrow = th64[~wide]
+            assert torch.equal(narrow, narrow.float().double())                 # float32-exact until the switch
+            assert not torch.equal(th64[wide], th64[wide].float().double())     # genuinely double after it
     for a, b, name in zip(res[0], res[1], ("theta^2", "squared jump", "move rate")):
         se = math.sqrt(a.var(ddof=1) / n + b.var(ddof=1) / n)
         assert abs(a.mean() - b.mean()) < 5 * se, (name, a.mean(), b.mean(), se)

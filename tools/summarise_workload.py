@@ -13,6 +13,7 @@ def newest(pattern):
 
 
 tag, wl, prefix, pat = sys.argv[1:5]
+name = sys.argv[5] if len(sys.argv) > 5 else wl            # name of the profiles/ files (e.g. glmcmc_fast for `glmcmc --fast-math`)
 rx = re.compile(pat)
 root = "gpurun_out/%s_%s" % (tag, wl)
 vals, per_kernel = {}, collections.defaultdict(dict)
@@ -38,7 +39,7 @@ kern = [r for r in csv.DictReader(open(stats_file)) if rx.search(r["Name"])]
 bench = json.loads(open(root + "/bench.json").read().strip().split("\n")[-1])
 cfg = bench.get("config", {})
 out = {"what": "rocprofv3 --pmc passes (one counter group per run) of `python3 bench.py --workload %s --steps 3 --warmup 1 "
-               "--no-cpu-baseline` on MI355X; averages per launch of the kernels matching /%s/" % (wl, pat),
+               "--no-cpu-baseline` on MI355X; averages per launch of the kernels matching /%s/%s" % (wl, pat, " (profiles name: %s)" % name if name != wl else ""),
        "round": 3, "workload": wl, "lib_sha16": open(root + "/lib_sha16.txt").read().strip(),
        "config": {"chains": cfg.get("chains_per_gpu"), "iters_per_launch": cfg.get("iters_per_step"), "batch_size": cfg.get("batch_size")},
        "raw_avg_per_launch": vals,
@@ -82,8 +83,8 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
     out["mfma"] = {"per_kernel": per,
                    "note": "v_mfma_f32_32x32x2_f32 = 4096 flop per wave-instruction, 64 cycles of a SIMD's matrix pipe; busy fraction = "
                            "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32 shader engines"}
-json.dump(out, open("profiles/%s_pmc_%s.json" % (prefix, wl), "w"), indent=1)
-shutil.copy(stats_file, "profiles/%s_kernel_stats_%s.csv" % (prefix, wl))
-shutil.copy(root + "/bench.json", "profiles/%s_bench_%s.json" % (prefix, wl))
+json.dump(out, open("profiles/%s_pmc_%s.json" % (prefix, name), "w"), indent=1)
+shutil.copy(stats_file, "profiles/%s_kernel_stats_%s.csv" % (prefix, name))
+shutil.copy(root + "/bench.json", "profiles/%s_bench_%s.json" % (prefix, name))
 print(json.dumps(out.get("derived"), indent=1), json.dumps(out.get("mfma"), indent=1)[:1500], out["kernel_trace"][:3])
 print("bench:", bench["value"], bench["unit"], bench["ms_per_step"])
