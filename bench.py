@@ -223,15 +223,39 @@ def lib_sha16():
     return h.hexdigest()[:16]
 
 
+def src_sha16():
+    """SHA-256 over the sources libglabc_hip.so is built from (csrc/*.hip, *.h, Makefile, include/*.h), in sorted order: the
+    second key of a counter file -- hipcc's objects are not byte-reproducible, so a clean rebuild of the SAME sources changes
+    lib_sha16 but not this"""
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "gl-abc-mcmc_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "glabc_*.h")) + [os.path.join(csrc, "Makefile")] +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    h = hashlib.sha256()
+    for p in files:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def counted(workload, n, K, batch=None):
     """profiles/r03_pmc_<workload>.json (tools/profile_workload.sh + summarise_workload.py): the rocprofv3 counters of exactly
     this configuration -- used ONLY while the library that runs is the build they were taken with (SHA-256 of
-    libglabc_hip.so) and the launch shape is the same; anything else returns None instead of a stale number."""
+    libglabc_hip.so; or, after a clean rebuild, the same kernel sources: src_sha16) and the launch shape is the same; anything
+    else returns None instead of a stale number."""
     try:
         with open(os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % workload)) as f:
             p = json.load(f)
         cfg = p["config"]
-        if p.get("lib_sha16") != lib_sha16() or cfg.get("chains") != n or cfg.get("iters_per_launch") != K:
+        if cfg.get("chains") != n or cfg.get("iters_per_launch") != K:
+            return None
+        if p.get("lib_sha16") == lib_sha16():
+            p["keyed_by"] = "libglabc_hip.so %s" % p["lib_sha16"]
+        elif p.get("src_sha16") and p["src_sha16"] == src_sha16():
+            p["keyed_by"] = "kernel sources %s (library rebuilt from the same sources)" % p["src_sha16"]
+        else:
             return None
         if batch is not None and cfg.get("batch_size") not in (None, batch):
             return None
@@ -246,7 +270,7 @@ def valu_block(p, workload, kernel_ms):
     insts = p["raw_avg_per_launch"]["SQ_INSTS_VALU"]
     wips = insts / (kernel_ms * 1e-3)
     peak = 1024 * 2.4e9 / 2              # MI355X_MICROARCH.md: wave64 v_fma_f32 = 2 cycles on a SIMD-32; 1024 SIMDs at 2.4 GHz
-    return {"source": "profiles/r03_pmc_%s.json (rocprofv3 --pmc, library %s) + this run's kernel time" % (workload, p["lib_sha16"]),
+    return {"source": "profiles/r03_pmc_%s.json (rocprofv3 --pmc, %s) + this run's kernel time" % (workload, p["keyed_by"]),
             "valu_insts_per_launch": insts, "valu_insts_per_group_step": d["valu_insts_per_group_step"],
             "waves_per_launch": d.get("waves_per_launch"), "wave_insts_per_s": wips,
             "simd_cycles_per_valu_inst": 1024 * 2.4e9 * kernel_ms * 1e-3 / insts,
@@ -309,7 +333,7 @@ def bench_nf(args):
                         "all_flop_TFLOPs": flop / (kernel_ms * 1e-3) / 1e12}}
     pm = counted("nf", None, None)
     if pm is not None and "mfma" in pm:
-        out["roofline"]["mfma_counters"] = {"source": "profiles/r03_pmc_nf.json (library %s)" % pm["lib_sha16"],
+        out["roofline"]["mfma_counters"] = {"source": "profiles/r03_pmc_nf.json (%s)" % pm["keyed_by"],
                                             "per_kernel": pm["mfma"]["per_kernel"]}
     if not args.no_cpu_baseline:
         host_blob = blob.cpu().contiguous()                   # the checker reads host memory
@@ -383,7 +407,7 @@ def bench_nf_train(args):
                         "kernel_ms": grad_ms}}
     pm = counted("nf_train", None, None)
     if pm is not None and "mfma" in pm:
-        out["roofline"]["mfma_counters"] = {"source": "profiles/r03_pmc_nf_train.json (library %s)" % pm["lib_sha16"],
+        out["roofline"]["mfma_counters"] = {"source": "profiles/r03_pmc_nf_train.json (%s)" % pm["keyed_by"],
                                             "per_kernel": pm["mfma"]["per_kernel"]}
     if not args.no_cpu_baseline:
         host_blob = flow.packed_params().cpu().contiguous()   # the checker reads host memory

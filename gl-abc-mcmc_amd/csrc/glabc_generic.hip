@@ -117,6 +117,7 @@ struct GenArgs {
     float* prior_cur;
     float* kern_cur;
     const float* q_cur;
+    const int32_t* n_valid;
     int32_t redraw_round;
     int32_t* n_redrawn;
 };
@@ -250,9 +251,12 @@ __global__ void __launch_bounds__(256) select_kernel(const GenArgs a)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= a.n_chains) return;
-    const int D = a.theta_dim, YD = a.y_dim, N = a.n_prop;
+    const int D = a.theta_dim, YD = a.y_dim;
     const int64_t C = a.n_chains;
     const bool is_global = (a.is_global[c] & 1) != 0;
+    // GLMCMC.py:67-70: proposals with a NaN coordinate were removed before the Model saw them (glabc_step_io.n_valid)
+    int N = a.n_prop;
+    if (a.n_valid && is_global) N = a.n_valid[c] < 0 ? 0 : (a.n_valid[c] < N ? a.n_valid[c] : N);
     const float prior_c = a.prior_cur[c], kern_c = a.kern_cur[c];
     uint32_t flags = a.flags ? a.flags[c] : 0u;
     float log_w = a.log_w ? a.log_w[c] : 0.0f;
@@ -494,6 +498,7 @@ static int pack_common(int algo, const glabc_dist* local, const glabc_dist* glob
     a->prior_cur = io->prior_cur;
     a->kern_cur = io->kern_cur;
     a->q_cur = io->q_cur;
+    a->n_valid = io->n_valid;
     return GLABC_OK;
 }
 

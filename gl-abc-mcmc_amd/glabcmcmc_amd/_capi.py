@@ -196,6 +196,7 @@ class StepIO(C.Structure):
         ("prior_cur", C.c_void_p),
         ("kern_cur", C.c_void_p),
         ("q_cur", C.c_void_p),
+        ("n_valid", C.c_void_p),
     ]
 
 

@@ -224,6 +224,10 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     lp = C.byref(local_desc) if local_desc is not None else None
     gp = C.byref(global_desc) if global_desc is not None else None
 
+    col_index = torch.arange(n, device=dev).view(1, n)
+    n_valid = torch.full((n,), N, dtype=torch.int32, device=dev)
+    if global_cb is not None and algo == _capi.ALGO_GLMCMC:
+        io.n_valid = n_valid.data_ptr()
     keep = {}                                              # tensors whose addresses the current StepIO holds
     speculating = [False]                                  # inside a captured iteration: count sentinel hits instead of redrawing
 
@@ -244,6 +248,17 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
                     z = torch.where(keep_rows.view(-1, 1), theta_prop, z)
                 theta_prop.copy_(z)
                 log_q.copy_(lq)
+                if algo == _capi.ALGO_GLMCMC:
+                    # GLMCMC.py:67-70: proposals with a NaN coordinate are dropped BEFORE the Model sees them; the weight vector
+                    # is then shorter.  Only a callback proposal can produce them.  Stays on the device: the chain's valid rows
+                    # move to the front in their order (the k-th survivor is simulated with the k-th noise row, as the
+                    # reference's generate_samples(Theta_prop0) draws for the shortened batch), glabc_select gets the count.
+                    bad = torch.isnan(theta_prop).any(1).view(N, n) & glob_rows.view(1, n)
+                    order = torch.argsort(bad.to(torch.uint8), dim=0, stable=True)
+                    rows = (order * n + col_index).view(-1)
+                    theta_prop.copy_(theta_prop[rows])
+                    log_q.copy_(log_q[rows])
+                    n_valid.copy_((N - bad.sum(0)).to(torch.int32))
             if local_cb is not None:                                   # Local_Proposal.sample(1) + Theta_old, GLMCMC.py:91
                 row0_local = local_cb.sample(n) + chains.theta.t()
                 theta_prop[:n] = torch.where(glob_rows.view(-1, 1), theta_prop[:n], row0_local)

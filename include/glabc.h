@@ -415,6 +415,11 @@ typedef struct glabc_step_io {
     float* kern_cur;               /* [n_chains] calculate_log_kernel(y_old) */
     const float* q_cur;            /* NULL (glabc_select evaluates the descriptor `global` at Theta_old) or [n_chains]
                                       Importance_Proposal.log_prob(Theta_old) from the caller */
+    const int32_t* n_valid;        /* NULL, or [n_chains]: GLMCMC.py:67-70 removes the proposals that have a NaN coordinate BEFORE
+                                      the Model sees them -- the weight vector is then shorter (torch.sum adds fewer terms, the index
+                                      counts the survivors).  Only a proposal given as a callback can produce such rows; the caller
+                                      moves them behind the chain's valid candidates (keeping their order) and says how many are
+                                      left: glabc_select uses rows 0 .. n_valid[c]-1 of chain c.  Ignored on the local branch. */
 } glabc_step_io;
 
 /* Philox slots of the local move's redraws (GLMCMC.py:92-93): round k of a chain reads blocks GLABC_SLOT_REDRAW + k*2 + b */

@@ -1949,14 +1949,18 @@ ORACLE_API int oracle_select(int algo, const glabc_dist* global, const glabc_cha
     if (!global && !io->q_cur) return GLABC_ERR_NULL;
     if (algo != GLABC_ALGO_GLOBALMCMC && (!c->log_w || !c->flags)) return GLABC_ERR_NULL;
     const int isir = algo != GLABC_ALGO_GLOBALMCMC;
-    const int d = io->theta_dim, yd = io->y_dim, N = io->n_prop;
+    const int d = io->theta_dim, yd = io->y_dim, N_all = io->n_prop;
     const int64_t C = c->n_chains;
-    float* lw = (float*)malloc(sizeof(float) * (size_t)(N + 1));
-    float* w = (float*)malloc(sizeof(float) * (size_t)(N + 1));
+    float* lw = (float*)malloc(sizeof(float) * (size_t)(N_all + 1));
+    float* w = (float*)malloc(sizeof(float) * (size_t)(N_all + 1));
     float* th_old = (float*)malloc(sizeof(float) * (size_t)d);
     if (!lw || !w || !th_old) { free(lw); free(w); free(th_old); return GLABC_ERR_ARG; }
     for (int64_t i = 0; i < C; ++i) {
         const int is_global = io->is_global[i] & 1;
+        /* GLMCMC.py:67-70: rows with a NaN coordinate are gone before generate_samples; the caller has compacted the chain's
+         * candidates and says how many survive */
+        int N = N_all;
+        if (io->n_valid && is_global) N = io->n_valid[i] < 0 ? 0 : (io->n_valid[i] < N_all ? io->n_valid[i] : N_all);
         const float prior_c = io->prior_cur[i], kern_c = io->kern_cur[i];
         for (int k = 0; k < d; ++k) th_old[k] = c->theta[k * c->stride + i];
         float q_state = 0.0f;

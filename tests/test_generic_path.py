@@ -661,3 +661,159 @@ def test_hip_propose_noise_rows_beyond_eight_proposal_words(hip, oracle, d, nd):
     assert np.array_equal(bits(got[G:-G].reshape(R, nd)), bits(h["noise"]))
     assert np.array_equal(buf["is_global"].cpu().numpy(), h["is_global"])
     assert np.array_equal(buf["u_res"].cpu().numpy(), h["u_res"])
+
+
+def _reference_isir_with_nan_rows(lw_old, theta_prop, prior_fn, kern_fn, log_q, u_res):
+    """GLMCMC.py:66-84 literally, in torch on the CPU, for ONE chain whose proposal returned `theta_prop` (N, d) and `log_q`:
+    rows with a NaN coordinate dropped (:67-70), weights of the survivors, torch.sum, weight_sampling's Python loop.  Returns
+    (index into the COMPACTED list incl. the current state at 0, or None; number of survivors)."""
+    has_nans = torch.isnan(theta_prop)
+    keep = torch.all(~has_nans, dim=1)
+    th, lq = theta_prop[keep].clone(), log_q[keep].clone()
+    log_weight0 = prior_fn(th) + kern_fn(th) - lq
+    log_weight = torch.cat((lw_old.view(-1), log_weight0))
+    weight = torch.exp(log_weight)
+    weight[torch.isnan(weight)] = 0.0
+    weight = weight / torch.sum(weight)
+    s, ind = 0, None
+    for j, w in enumerate(weight.tolist()):
+        s = s + w
+        if u_res < s:
+            ind = j
+            break
+    return ind, int(keep.sum())
+
+
+def test_oracle_select_drops_nan_proposals_like_the_reference(oracle):
+    """GLMCMC.py:67-70 (glabc_step_io.n_valid): a callback proposal hands back rows with NaN coordinates; the caller compacts
+    the chain's candidates and glabc_select / oracle_select work on the survivors -- the index equals the one the reference's
+    lines give on the same numbers (torch.sum over the shorter vector, the same running sum), chain by chain."""
+    rng = np.random.default_rng(5)
+    n, N, d = 300, 7, 2
+    C_ = n
+    theta_prop = rng.standard_normal((N, n, d)).astype(np.float32)
+    bad = rng.random((N, n)) < 0.2
+    bad[:, :5] = False
+    bad[:, 5] = True                                                           # a chain with every proposal NaN: stays
+    theta_prop[bad, rng.integers(0, d, bad.sum())] = np.nan
+    prior = (-0.5 * (np.nan_to_num(theta_prop) ** 2).sum(-1)).astype(np.float32)
+    kern = (-rng.random((N, n)) * 3).astype(np.float32)
+    log_q = (-rng.random((N, n)) * 2).astype(np.float32)
+    u_res = rng.random(n)
+    lw_old = (-rng.random(n) * 2).astype(np.float32)
+    # what the caller does (generic.run): survivors first, in their order; NaN rows behind them
+    order = np.argsort(bad.astype(np.uint8), axis=0, kind="stable")
+    take = lambda a: np.take_along_axis(a, order if a.ndim == 2 else order[..., None], axis=0)      # noqa: E731
+    tp_c, pr_c, kn_c, lq_c = take(theta_prop), take(prior), take(kern), take(log_q)
+    n_valid = (N - bad.sum(0)).astype(np.int32)
+    hc = oracle_lib.HostChains(np.zeros((n, d), np.float32), np.zeros((n, 2), np.float32))
+    hc.log_w[:] = lw_old
+    hc.flags[:] = 0
+    cs = hc.struct()
+    flat = lambda a: np.ascontiguousarray(a.reshape(N * n, -1) if a.ndim == 3 else a.reshape(N * n))   # noqa: E731
+    buf = dict(theta_prop=flat(tp_c), log_q=flat(lq_c), y=np.zeros((N * n, 2), np.float32), prior=flat(pr_c), kern=flat(kn_c),
+               log_u=np.zeros(n, np.float32), u_res=u_res.copy(), is_global=np.ones(n, np.int32),
+               prior_cur=np.zeros(n, np.float32), kern_cur=np.zeros(n, np.float32), q_cur=np.zeros(n, np.float32))
+    io = A.StepIO(N, d, 2, 0, buf["theta_prop"].ctypes.data, buf["log_q"].ctypes.data, None, buf["log_u"].ctypes.data,
+                  buf["u_res"].ctypes.data, buf["is_global"].ctypes.data, buf["y"].ctypes.data, buf["prior"].ctypes.data,
+                  buf["kern"].ctypes.data, buf["prior_cur"].ctypes.data, buf["kern_cur"].ctypes.data, buf["q_cur"].ctypes.data,
+                  n_valid.ctypes.data)
+    run, keep = oracle_lib.make_run(seed=1, step0=1, n_steps=1, gf=1.0, batch=N)
+    assert oracle.oracle_select(A.ALGO_GLMCMC, None, C.byref(cs), C.byref(run), C.byref(io)) == 0
+    moved = (buf["is_global"] & 2) != 0
+    checked = 0
+    for c in range(n):
+        th = torch.from_numpy(theta_prop[:, c, :])
+        pr_rows, kn_rows = torch.from_numpy(prior[:, c]), torch.from_numpy(kern[:, c])
+        keep_rows = ~torch.isnan(th).any(1)
+        ind, nv = _reference_isir_with_nan_rows(torch.tensor([lw_old[c]]), th, lambda t: pr_rows[keep_rows], lambda t: kn_rows[keep_rows],
+                                                torch.from_numpy(log_q[:, c]), float(u_res[c]))
+        assert nv == n_valid[c]
+        want_move = ind is not None and ind != 0
+        assert bool(moved[c]) == want_move, c
+        if want_move:
+            survivors = np.flatnonzero(~bad[:, c])
+            assert np.array_equal(bits(hc.theta[:, c]), bits(theta_prop[survivors[ind - 1], c]))
+            checked += 1
+    assert checked > 50 and not moved[5] and (n_valid < N).sum() > 100
+
+
+@pytest.mark.gpu
+def test_hip_select_drops_nan_proposals(hip, oracle):
+    """glabc_select with glabc_step_io.n_valid == the CPU checker (which the test above holds to the reference's lines), and the
+    package's GLMCMC with a callback proposal that returns NaN rows runs, never moves to one, and reaches the posterior"""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import distribution, engine
+    rng = np.random.default_rng(6)
+    n, N, d = 1000, 6, 2
+    dev = torch.device("cuda", 0)
+    theta_prop = rng.standard_normal((N * n, d)).astype(np.float32)
+    n_valid = rng.integers(0, N + 1, n).astype(np.int32)
+    for c in range(n):
+        theta_prop[np.arange(n_valid[c], N) * n + c] = np.nan
+    prior = (-0.5 * (np.nan_to_num(theta_prop) ** 2).sum(-1)).astype(np.float32)
+    prior[np.isnan(theta_prop).any(1)] = np.nan
+    kern, log_q = (-rng.random(N * n) * 3).astype(np.float32), (-rng.random(N * n) * 2).astype(np.float32)
+    u_res, lw_old = rng.random(n), (-rng.random(n) * 2).astype(np.float32)
+    outs = []
+    for side in ("hip", "oracle"):
+        if side == "hip":
+            chains = engine.ChainBatch(torch.zeros(n, d), torch.zeros(n, 2), dev)
+            chains.log_w.copy_(torch.from_numpy(lw_old))
+            chains.flags.zero_()
+            cs = chains.struct()
+            t = {k: torch.from_numpy(v).to(dev) for k, v in dict(theta_prop=theta_prop, log_q=log_q, y=np.zeros((N * n, 2), np.float32),
+                 prior=prior, kern=kern, log_u=np.zeros(n, np.float32), u_res=u_res, is_global=np.ones(n, np.int32),
+                 prior_cur=np.zeros(n, np.float32), kern_cur=np.zeros(n, np.float32), q_cur=np.zeros(n, np.float32), n_valid=n_valid).items()}
+            p = lambda k: t[k].data_ptr()                                      # noqa: E731
+        else:
+            hc = oracle_lib.HostChains(np.zeros((n, d), np.float32), np.zeros((n, 2), np.float32))
+            hc.log_w[:] = lw_old
+            hc.flags[:] = 0
+            cs = hc.struct()
+            t = dict(theta_prop=theta_prop.copy(), log_q=log_q.copy(), y=np.zeros((N * n, 2), np.float32), prior=prior.copy(), kern=kern.copy(),
+                     log_u=np.zeros(n, np.float32), u_res=u_res.copy(), is_global=np.ones(n, np.int32), prior_cur=np.zeros(n, np.float32),
+                     kern_cur=np.zeros(n, np.float32), q_cur=np.zeros(n, np.float32), n_valid=n_valid.copy())
+            p = lambda k: t[k].ctypes.data                                     # noqa: E731
+        io = A.StepIO(N, d, 2, 0, p("theta_prop"), p("log_q"), None, p("log_u"), p("u_res"), p("is_global"), p("y"), p("prior"), p("kern"),
+                      p("prior_cur"), p("kern_cur"), p("q_cur"), p("n_valid"))
+        if side == "hip":
+            run = A.Run()
+            run.seed, run.step0, run.n_steps, run.global_frequency, run.batch_size = 1, 1, 1, 1.0, N
+            assert hip.glabc_select(A.ALGO_GLMCMC, None, C.byref(cs), C.byref(run), C.byref(io), None) == 0
+            torch.cuda.synchronize()
+            outs.append((chains.theta.cpu().numpy(), chains.log_w.cpu().numpy(), t["is_global"].cpu().numpy()))
+        else:
+            run, keep = oracle_lib.make_run(seed=1, step0=1, n_steps=1, gf=1.0, batch=N)
+            assert oracle.oracle_select(A.ALGO_GLMCMC, None, C.byref(cs), C.byref(run), C.byref(io)) == 0
+            outs.append((hc.theta, hc.log_w, t["is_global"]))
+    for x, y in zip(*outs):
+        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+    assert not np.isnan(outs[0][0]).any() and ((outs[0][2] & 2) != 0).sum() > 100
+
+    class NanProposal:
+        """an importance proposal object (callbacks only) that returns a NaN coordinate in a fifth of its rows"""
+
+        def __init__(self):
+            self.base = distribution.DiagGaussian(2, torch.zeros(2), torch.zeros(2))
+
+        def forward(self, num_samples=1):
+            z, lq = self.base.forward(num_samples)
+            z = z.clone()
+            z[torch.rand(num_samples) < 0.2, 0] = float("nan")
+            return z, lq
+
+        def log_prob(self, z):
+            return self.base.log_prob(z.cpu()).to(z.device)
+
+    torch.manual_seed(3)
+    m = TorchMixture(2, 0.3)
+    lp = distribution.DiagGaussian(2, torch.zeros(2), torch.log(torch.tensor([0.3, 0.3])))
+    nch, T = 4096, 200
+    th0 = torch.full((nch, 2), 1.3)
+    mom = engine.Moments(nch, 2, dev)
+    out = g_.GLMCMC(m, T + 1, th0, th0 + 0.2 * torch.randn(nch, 2), lp, None, 0.8, NanProposal(), 6, seed=4, stats=mom, verbose=False,
+                    return_device=True)
+    assert torch.isfinite(out).all()
+    sq = float(mom.second_moment().diagonal(dim1=1, dim2=2).mean())
+    assert 1.7 < sq < 2.5, sq

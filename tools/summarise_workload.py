@@ -34,13 +34,28 @@ for d in ("pmc_sq", "pmc_mem_r", "pmc_mem_w", "pmc_mfma"):
         vals[k] = acc[k] / cnt[k]
     for (kn, c) in acck:
         per_kernel[kn][c] = acck[(kn, c)] / cntk[(kn, c)]
+
+
+def src_sha():
+    """hash of the kernel sources the profiled library was built from (bench.src_sha16): written on the GPU box by
+    tools/profile_workload.sh; for an older run, taken from this tree if its library is still the profiled one"""
+    p = root + "/src_sha16.txt"
+    if os.path.exists(p):
+        return open(p).read().strip()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    if bench.lib_sha16() == open(root + "/lib_sha16.txt").read().strip():
+        return bench.src_sha16()
+    return None
+
+
 stats_file = newest(root + "/trace/**/*kernel_stats.csv")
 kern = [r for r in csv.DictReader(open(stats_file)) if rx.search(r["Name"])]
 bench = json.loads(open(root + "/bench.json").read().strip().split("\n")[-1])
 cfg = bench.get("config", {})
 out = {"what": "rocprofv3 --pmc passes (one counter group per run) of `python3 bench.py --workload %s --steps 3 --warmup 1 "
                "--no-cpu-baseline` on MI355X; averages per launch of the kernels matching /%s/%s" % (wl, pat, " (profiles name: %s)" % name if name != wl else ""),
-       "round": 3, "workload": wl, "lib_sha16": open(root + "/lib_sha16.txt").read().strip(),
+       "round": 3, "workload": wl, "lib_sha16": open(root + "/lib_sha16.txt").read().strip(), "src_sha16": src_sha(),
        "config": {"chains": cfg.get("chains_per_gpu"), "iters_per_launch": cfg.get("iters_per_step"), "batch_size": cfg.get("batch_size")},
        "raw_avg_per_launch": vals,
        "kernel_trace": [{"name": k["Name"][:140], "avg_ns": float(k["AverageNs"]), "min_ns": float(k["MinNs"]), "calls": int(k["Calls"])}
