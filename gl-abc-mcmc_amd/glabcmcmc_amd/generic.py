@@ -167,8 +167,8 @@ class ProposalCallbacks:
 
 def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_Proposal, filelocation, global_frequency,
         batch_size, csv_variant, *, seed=None, device=None, chain0=0, record_history=True, stats=None, return_device=False,
-        verbose=True, state_out=None, callback_device="auto", sentinel_redraw=True, max_redraws=100000, progress=None,
-        graph="auto"):
+        verbose=True, state_out=None, callback_device="auto", sentinel_redraw=True, max_redraws=100000, max_graph_rounds=32,
+        progress=None, graph="auto"):
     """GLMCMC (algo = _capi.ALGO_GLMCMC, GLMCMC.py:24-137) or GlobalMCMC (_capi.ALGO_GLOBALMCMC, GlobalMCMC.py:6-98) with
     the Model -- and, if need be, the proposals -- as callbacks.  Same return value and side effects as the fused path.
 
@@ -176,7 +176,8 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     tensors, no sentinel check (GlobalMCMC, or sentinel_redraw=False) -- is captured ONCE as a hipGraph (torch.cuda.graph:
     the two HIP kernels with the iteration index in device memory, glabc_run.step0_device, plus the Model's own kernels) and
     replayed; 'auto' falls back to launching eagerly when the capture is not possible (e.g. a callback that synchronises).
-    With the sentinel check on (GLMCMC's default) the replay is speculative, see below: same results as the eager loop."""
+    With the sentinel check on (GLMCMC's default) the replay is speculative, see below: same results as the eager loop; a prior
+    that does return the sentinel keeps the run a replayed graph, with up to max_graph_rounds redraw rounds inside it."""
     lib = _capi.lib()
     dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
     n, d, yd = chains.n, chains.d, chains.yd
@@ -229,7 +230,8 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
     if global_cb is not None and algo == _capi.ALGO_GLMCMC:
         io.n_valid = n_valid.data_ptr()
     keep = {}                                              # tensors whose addresses the current StepIO holds
-    speculating = [False]                                  # inside a captured iteration: count sentinel hits instead of redrawing
+    speculating = [False]                                  # inside a captured iteration: bounded redraw rounds + a count
+    graph_rounds = [0]                                     # redraw rounds (GLMCMC.py:92-93) held by the captured iteration
 
     def iteration(i):
         """one iteration on torch's current stream; i = None: the index is read from step_t on the device (graph)"""
@@ -265,11 +267,18 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
         prior_prop = model.prior(theta_prop)                           # GLMCMC.py:74,92,96
         io.prior_prop = prior_prop.data_ptr()
         if sentinel_redraw and algo == _capi.ALGO_GLMCMC and speculating[0]:
-            # captured form: the redraw loop needs the host, so local candidates that hit the sentinel are only COUNTED (one
-            # launch of the redraw kernel: its device counter is never zeroed here), and the replay loop below rolls the segment
-            # back and redoes it eagerly if the count is ever non-zero
-            _capi.check(lib.glabc_propose_redraw(lp, C.byref(cs), C.byref(run_), C.byref(io), 1, violations.data_ptr(), stream),
-                        "glabc_propose_redraw")
+            # captured form: the reference's loop (GLMCMC.py:92-93) ends on a host read, which a hipGraph cannot hold, so the
+            # capture holds a BOUNDED number of its rounds -- redraw the local candidates whose prior is the sentinel (a
+            # round without one is a no-op: the kernel touches nothing and the prior of an unchanged row is the same number),
+            # evaluate the prior again -- and one more launch of the redraw kernel that only COUNTS the candidates still at the
+            # sentinel after them (its device counter is never zeroed here).  The replay loop below reads the count once per
+            # segment; if it is ever non-zero it restores the segment's start state and captures again with more rounds.
+            for rnd in range(1, graph_rounds[0] + 1):
+                _capi.check(lib.glabc_propose_redraw(lp, C.byref(cs), C.byref(run_), C.byref(io), rnd, n_redrawn.data_ptr(),
+                                                     stream), "glabc_propose_redraw")
+                prior_prop[:n] = model.prior(theta_prop[:n])
+            _capi.check(lib.glabc_propose_redraw(lp, C.byref(cs), C.byref(run_), C.byref(io), graph_rounds[0] + 1,
+                                                 violations.data_ptr(), stream), "glabc_propose_redraw")
         elif sentinel_redraw and algo == _capi.ALGO_GLMCMC:            # GLMCMC.py:92-93
             for rnd in range(1, max_redraws + 1):
                 if local_cb is None:
@@ -301,10 +310,13 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
         _capi.check(lib.glabc_select(algo, gp, C.byref(cs), C.byref(run_), C.byref(io), stream), "glabc_select")
 
     # Graph replay.  Without a sentinel check (GlobalMCMC, sentinel_redraw=False) an iteration never visits the host.  WITH it
-    # (the default for GLMCMC) the replay is speculative: almost no prior ever returns the sentinel, so the captured iteration
-    # only counts the local candidates that hit it; the count is read once per segment of 64 iterations, and if it is ever
-    # non-zero the segment's start state is restored and the rest of the run goes through the eager loop with the reference's
-    # redraw -- the Philox draws depend on (chain, iteration) only, so the result is the eager path's either way.
+    # (the default for GLMCMC) the replay is speculative: almost no prior ever returns the sentinel, so the first capture holds
+    # no redraw round at all and only counts the local candidates that hit it; the count is read once per segment of 64
+    # iterations.  When it is non-zero the segment's start state is restored and the iteration is captured AGAIN with 2, 4, ...
+    # max_graph_rounds redraw rounds inside the graph (device side, no host read): a Model whose prior does return the sentinel
+    # keeps running as a replayed graph.  Only a prior that still returns it after max_graph_rounds redraws of one candidate sends
+    # the rest of the run through the eager loop.  The Philox draws depend on (chain, iteration, round) only, so every form gives
+    # the eager path's chains.
     plain = local_cb is None and global_cb is None and progress is None
     speculative = plain and sentinel_redraw and algo == _capi.ALGO_GLMCMC
     capturable = plain
@@ -336,50 +348,70 @@ def run(algo, ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal, Global_
                     b_.copy_(a_)
 
             step_t = torch.tensor([i], dtype=torch.int32, device=dev)          # the iteration index, on the device
-            run_.step0, run_.step0_device = 1, step_t.data_ptr()
-            run_.history = hist_ptr + hist_row_bytes if hist is not None else None   # row 0 of `history` = iteration 1
-            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(dev)
+
+            def capture():
+                """one iteration (graph_rounds[0] redraw rounds inside) as a hipGraph reading its index from step_t; the
+                warm-up run of the captured form IS iteration i of the chains.  None when it cannot be captured."""
+                step_t.fill_(i)
+                violations.zero_()
+                run_.step0, run_.step0_device = 1, step_t.data_ptr()
+                run_.history = hist_ptr + hist_row_bytes if hist is not None else None   # row 0 of `history` = iteration 1
+                g_ = torch.cuda.CUDAGraph()
+                try:
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):                               # warm the captured form once (step_t advances)
+                        iteration(None)
+                        step_t.add_(1)
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                    with torch.cuda.graph(g_):
+                        iteration(None)
+                        step_t.add_(1)
+                except Exception:                                               # not capturable after all: launch eagerly
+                    if graph is True:
+                        raise
+                    torch.cuda.synchronize(dev)
+                    g_ = None
+                finally:
+                    run_.step0_device = None
+                return g_
+
             speculating[0] = speculative
             snapshot()
-            try:
-                side = torch.cuda.Stream(dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):                                   # warm the captured form once (step_t advances)
-                    iteration(None)
-                    step_t.add_(1)
-                torch.cuda.current_stream(dev).wait_stream(side)
-                with torch.cuda.graph(g):
-                    iteration(None)
-                    step_t.add_(1)
-            except Exception:                                                   # not capturable after all: launch eagerly
-                if graph is True:
-                    raise
-                torch.cuda.synchronize(dev)
-                g = None
-            run_.step0_device = None
+            g = capture()
             done = 1 if g is not None else 0                                    # the warm-up iteration belongs to the first segment
             if g is None:                                                       # (a failed capture may have run part of an iteration)
                 restore()
-            while g is not None and i + done < num_ite:
+            while g is not None and i + done <= num_ite:
                 k = min(64 - done, num_ite - i - done)
                 for _ in range(k):
                     g.replay()
                 done += k
                 if speculative and int(violations.item()) != 0:                 # one synchronisation per segment
-                    restore()
-                    g = None
+                    restore()                                                   # back to iteration i
                     if state_out is not None:
-                        state_out["graph_rolled_back_at"] = i
-                    break
+                        state_out.setdefault("graph_rolled_back_at", i)
+                    graph_rounds[0] = max(2, 2 * graph_rounds[0])
+                    if graph_rounds[0] > max_graph_rounds:
+                        g = None
+                        break
+                    g = capture()
+                    done = 1 if g is not None else 0
+                    if g is None:
+                        restore()
+                    continue
                 i += done
                 done = 0
-                if speculative and i < num_ite:
+                if i >= num_ite:
+                    break
+                if speculative:
                     snapshot()
             speculating[0] = False
             if g is not None:
                 i = num_ite
                 if state_out is not None:
                     state_out["graph"] = True
+                    state_out["graph_redraw_rounds"] = graph_rounds[0]
         for i in range(i, num_ite):
             iteration(i)
             if progress is not None:

@@ -11,6 +11,12 @@ the fixture stores their means over chunks of chains, from which the test derive
 
     python tests/golden/make_glmala_stats.py run  [--workers 5] [--chains 150000] [--out /tmp/glmala_stats]
     python tests/golden/make_glmala_stats.py collect [--out /tmp/glmala_stats]     # -> tests/golden/glmala_stats.npz
+
+The per-chain rows live only in --out (scratch); the fixture keeps the chunk means.  To EXTEND a committed fixture after the
+scratch directory is gone, run further chunks (`run --first-chunk K0`, K0 beyond every chunk the fixture was made from: chain
+ids, and with them every seed, are k * 64 + c) and `collect --merge`: the fixture's chunk means and the new ones are pooled
+(mean of chunk means; standard error = their standard deviation / sqrt(number of chunks) -- chunks are independent and of
+equal size, so this is the same estimator as the per-chain one).
 """
 import argparse
 import contextlib
@@ -94,26 +100,39 @@ def main():
     ap.add_argument("--workers", type=int, default=5)
     ap.add_argument("--chains", type=int, default=150000)
     ap.add_argument("--out", default="/tmp/glmala_stats")
+    ap.add_argument("--first-chunk", type=int, default=0)
+    ap.add_argument("--merge", action="store_true", help="collect: pool with the chunk means of the committed fixture")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     if a.what == "run":
         import multiprocessing as mp
         n_chunks = (a.chains + CHUNK - 1) // CHUNK
         with mp.Pool(a.workers) as pool:
-            for i, k in enumerate(pool.imap_unordered(run_chunk, [(k, a.out) for k in range(n_chunks)])):
+            for i, k in enumerate(pool.imap_unordered(run_chunk, [(k, a.out) for k in range(a.first_chunk, a.first_chunk + n_chunks)])):
                 if i % 20 == 0:
                     print("chunk %d done (%d / %d)" % (k, i + 1, n_chunks), flush=True)
         return
     files = sorted(glob.glob(os.path.join(a.out, "chunk_*.npy")))
     files = [f for f in files if not f.endswith(".tmp.npy")]
     rows = np.stack([np.load(f) for f in files])                 # (chunks, CHUNK, stats)
-    flat = rows.reshape(-1, rows.shape[-1])
-    mean, se = flat.mean(0), flat.std(0, ddof=1) / np.sqrt(flat.shape[0])
-    np.savez_compressed(os.path.join(HERE, "glmala_stats.npz"), chunk_means=rows.mean(1), n_chains=np.array(flat.shape[0]),
+    fixture = os.path.join(HERE, "glmala_stats.npz")
+    if a.merge:
+        old = np.load(fixture)
+        assert int(old["chunk"]) == CHUNK and str(old["cfg"]) == repr(CFG) and str(old["names"]) == repr(STAT_NAMES)
+        ids = [int(os.path.basename(f)[6:12]) for f in files]
+        assert min(ids) >= old["chunk_means"].shape[0], "new chunks must lie beyond the fixture's (seeds are per chain id)"
+        cm = np.concatenate([old["chunk_means"], rows.mean(1)])
+        n_chains = cm.shape[0] * CHUNK
+        mean, se = cm.mean(0), cm.std(0, ddof=1) / np.sqrt(cm.shape[0])
+    else:
+        flat = rows.reshape(-1, rows.shape[-1])
+        cm, n_chains = rows.mean(1), flat.shape[0]
+        mean, se = flat.mean(0), flat.std(0, ddof=1) / np.sqrt(flat.shape[0])
+    np.savez_compressed(fixture, chunk_means=cm, n_chains=np.array(n_chains),
                         chunk=np.array(CHUNK), mean=mean, se=se, names=np.array(repr(STAT_NAMES)), cfg=np.array(repr(CFG)))
     for n, m, s in zip(STAT_NAMES, mean, se):
         print("%-12s %.6f +- %.6f  (rel %.2e)" % (n, m, s, s / abs(m) if m else 0))
-    print("%d chains in %d chunks" % (flat.shape[0], len(files)))
+    print("%d chains in %d chunks (%d new files)" % (n_chains, cm.shape[0], len(files)))
 
 
 if __name__ == "__main__":

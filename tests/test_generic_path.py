@@ -590,8 +590,10 @@ def test_hip_theta_dim_beyond_the_descriptor_limit(hip):
 def test_hip_speculative_graph_replay_with_the_sentinel_check(hip, oracle):
     """GLMCMC's default (sentinel check on) replays a captured iteration speculatively: (a) a prior that never returns the
     sentinel -- the whole run is replayed and equals the eager loop bit for bit over several 64-iteration segments; (b) a prior
-    that does -- the first hit rolls the segment back and the eager loop with the reference's redraw takes over: still the
-    checker's chains."""
+    that does -- the first hit rolls the segment back and the iteration is captured again with the reference's redraw loop
+    (GLMCMC.py:92-93) as a bounded number of rounds INSIDE the graph, doubled until a segment passes: the run stays a replayed
+    graph and still gives the checker's chains; (c) with fewer rounds allowed in a graph than the prior needs, the rest of the run
+    goes through the eager loop: the same chains again."""
     import glabcmcmc_amd as g_
     from test_stream_independence import abs_gauss_model, proposals
     g = load_golden("glmcmc_philox_bench")
@@ -621,8 +623,17 @@ def test_hip_speculative_graph_replay_with_the_sentinel_check(hip, oracle):
     st = {}
     out = g_.GLMCMC(BoxedModel(bm), T + 1, torch.from_numpy(theta0), torch.from_numpy(y0b), FixedDescriptor(lp), None, 0.3,
                     FixedDescriptor(ip), 3, seed=5, verbose=False, state_out=st)
-    assert st.get("graph_rolled_back_at") == 4 and not st.get("graph")
+    assert st.get("graph_rolled_back_at") == 4 and st.get("graph") and 2 <= st["graph_redraw_rounds"] <= 32
     assert np.array_equal(bits(out.numpy()[1:].transpose(0, 2, 1)), bits(want)) and hc.redraws > 100
+    eager = g_.GLMCMC(BoxedModel(bm), T + 1, torch.from_numpy(theta0), torch.from_numpy(y0b), FixedDescriptor(lp), None, 0.3,
+                      FixedDescriptor(ip), 3, seed=5, verbose=False, graph=False)
+    assert np.array_equal(bits(out.numpy()), bits(eager.numpy()))
+    # (c)
+    st = {}
+    out = g_.GLMCMC(BoxedModel(bm), T + 1, torch.from_numpy(theta0), torch.from_numpy(y0b), FixedDescriptor(lp), None, 0.3,
+                    FixedDescriptor(ip), 3, seed=5, verbose=False, state_out=st, max_graph_rounds=1)
+    assert st.get("graph_rolled_back_at") == 4 and not st.get("graph")
+    assert np.array_equal(bits(out.numpy()), bits(eager.numpy()))
 
 
 @pytest.mark.gpu
