@@ -45,6 +45,12 @@ static_assert((L_W2 * 4) % 16 == 0 && L_W2 + NF_H * NF_H == NF_BLOCK_FLOATS, "LD
 #ifndef GLABC_NF_WAVES
 #define GLABC_NF_WAVES 12
 #endif
+#ifndef GLABC_NF_GROUPED
+#define GLABC_NF_GROUPED 1     // form 2: a group's eight MFMAs issued back to back behind their operands' vector instructions
+#endif
+#ifndef GLABC_NF_FORM
+#define GLABC_NF_FORM 2        // how a wavefront walks a pair-coupling: 0 k outermost, 1 output tile outermost, 2 = 1 + fenced prefetch
+#endif
 // waves per workgroup (one workgroup per CU).  12 = three per SIMD: with the rows' state in LDS and the vectors addressed
 // from one base register the pair kernel needs 168 VGPRs (no scratch), so three waves fit a SIMD's 512 and one wave's
 // LDS / VALU / epilogue gaps are filled by two others' MFMAs: 8 waves 104, 12 waves 112 TFLOP/s (profiles/r02_nf_*)
@@ -233,6 +239,131 @@ __device__ __forceinline__ void coupling_params2_tile_outer(const float* __restr
     log_s_b = ((half ? qb1 : pb1) + (half ? pb1 : qb1)) + b31;
 }
 
+// The tile-outer form with the operand fetch REALLY one group ahead (the default since round 3b).  In nf_tile_pass the source
+// asks for group g + 1's operands at the top of group g, but nothing holds the compiler to it: it sinks the ds_reads to the end of
+// the group, next to their first use, and the wavefront then sits in s_waitcnt for an LDS round trip at the head of EVERY group
+// of 8 MFMAs (19 % of the wave cycles parked, profiles/r03b_nf_wait.txt) -- covered only as far as the SIMD's other wavefronts
+// happen to have MFMAs queued.  Here the fetch is fenced in by scheduling barriers on both sides, and everything a group needs
+// from LDS comes that way: the four k steps' W1 / b1 / W2^T operands, the W3 pair of the hidden unit the group reduces, and
+// -- one register per group, into the registers the first MFMAs of the tile have just freed -- the next tile's b2, which
+// initialises the accumulators as the C operand of that tile's first MFMA pair instead of through sixteen exposed reads and
+// moves.  The last group of a tile fetches the first group of the next one; after tile 3 that is tile 0 of the wavefront's NEXT
+// pair (same coupling, same weights), so a wavefront fetches operands on the critical path once per coupling, not per group.
+// Same bits: every accumulator is the same k-ordered chain from b2, the W3 sums visit the hidden units in the same order.
+struct NfOps {
+    float w[4], bi[4], wv[4];     // W1[k], b1[k], W2^T[k][this lane's output unit] of the group's four k steps (k = 2 sn + half)
+    float2 v;                     // (W3[0][i], W3[1][i]) of the previous tile's hidden unit this group reduces
+};
+
+__device__ __forceinline__ void nf_fetch_ops(const float* __restrict__ lds, int half, int col, int t, int g, NfOps& o)
+{
+    const float* w1 = lds + L_W1 + half;
+    const float* bb1 = lds + L_B1 + half;
+    const float* wt = lds + L_W2 + half * NF_H + col + 32 * t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int sn = 4 * g + q;
+        o.w[q] = w1[2 * sn];
+        o.bi[q] = bb1[2 * sn];
+        o.wv[q] = wt[2 * sn * NF_H];
+    }
+    if (t > 0) {
+        const int i = 32 * (t - 1) + (g & 3) + 8 * (g >> 2) + 4 * half;
+        o.v = *reinterpret_cast<const float2*>(lds + L_V4 + 4 * i + 1);
+    }
+}
+
+__device__ __forceinline__ void nf_fetch_bias(const float* __restrict__ lds, int half, int t, f32x16& c)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = lds[L_V4 + 4 * (32 * t + (r & 3) + 8 * (r >> 2) + 4 * half)];
+}
+
+template <int T>
+__device__ __forceinline__ void nf_tile_pass_ahead(const float* __restrict__ lds, float z0a, float z0b, int half, int col, f32x16& xa,
+                                                   f32x16& xb, const f32x16& ya, const f32x16& yb, NfOps& cur, f32x16& c, float& pa0,
+                                                   float& pa1, float& pb0, float& pb1)
+{
+    constexpr int TN = (T + 1) & 3;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        NfOps nxt;
+        if (g < 15) nf_fetch_ops(lds, half, col, T, g + 1, nxt);
+        else nf_fetch_ops(lds, half, col, TN, 0, nxt);
+        f32x16 cn = c;
+        if (g >= 1) {                                                  // the next tile's b2: registers 0 and 15 in group 1, g in group g
+            const int r = g == 1 ? 0 : g;
+            cn[r] = lds[L_V4 + 4 * (32 * TN + (r & 3) + 8 * (r >> 2) + 4 * half)];
+            if (g == 1) cn[1] = lds[L_V4 + 4 * (32 * TN + 1 + 4 * half)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the group's eight B operands first, then its eight MFMAs back to back: a vector instruction between two MFMAs of one
+        // wavefront costs the matrix pipe ~12 cycles for the switch, whatever it is (tools/ubench/mfma_valu_fill.hip: 8 MFMAs then
+        // their 24 v_fma 133 TFLOP/s against 129 interleaved one to three, two wavefronts per SIMD)
+        float ha[4], hb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ha[q] = __builtin_fmaxf(__builtin_fmaf(cur.w[q], z0a, cur.bi[q]), 0.0f);
+            hb[q] = __builtin_fmaxf(__builtin_fmaf(cur.w[q], z0b, cur.bi[q]), 0.0f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (g == 0 && q == 0) {
+                xa = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.wv[q], ha[q], c, 0, 0, 0);
+                xb = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.wv[q], hb[q], c, 0, 0, 0);
+            } else {
+                xa = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.wv[q], ha[q], xa, 0, 0, 0);
+                xb = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.wv[q], hb[q], xb, 0, 0, 0);
+            }
+        }
+#if GLABC_NF_GROUPED
+        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);            // VALU: the eight fma + max
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);             // MFMA
+#endif
+        if constexpr (T > 0) {                                         // hidden unit g of the PREVIOUS tile, in register order
+            const float qa = __builtin_fmaxf(ya[g], 0.0f), qb = __builtin_fmaxf(yb[g], 0.0f);
+            pa0 = __builtin_fmaf(cur.v.x, qa, pa0);
+            pa1 = __builtin_fmaf(cur.v.y, qa, pa1);
+            pb0 = __builtin_fmaf(cur.v.x, qb, pb0);
+            pb1 = __builtin_fmaf(cur.v.y, qb, pb1);
+        }
+        cur = nxt;
+        c = cn;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ops / c: in = group 0 of tile 0 and b2 of tile 0 (nf_fetch_ops / nf_fetch_bias at the head of a coupling); out = the same again, for
+// the wavefront's next pair of this coupling
+__device__ __forceinline__ void coupling_params2_ahead(const float* __restrict__ lds, float z0a, float z0b, int lane, NfOps& ops, f32x16& c,
+                                                       float& shift_a, float& log_s_a, float& shift_b, float& log_s_b)
+{
+    const int half = lane >> 5, col = lane & 31;
+    f32x16 a0, b0, a1, b1, a2, b2, a3, b3;
+    float pa0 = 0.0f, pa1 = 0.0f, pb0 = 0.0f, pb1 = 0.0f;
+    nf_tile_pass_ahead<0>(lds, z0a, z0b, half, col, a0, b0, a0, b0, ops, c, pa0, pa1, pb0, pb1);
+    nf_tile_pass_ahead<1>(lds, z0a, z0b, half, col, a1, b1, a0, b0, ops, c, pa0, pa1, pb0, pb1);
+    nf_tile_pass_ahead<2>(lds, z0a, z0b, half, col, a2, b2, a1, b1, ops, c, pa0, pa1, pb0, pb1);
+    nf_tile_pass_ahead<3>(lds, z0a, z0b, half, col, a3, b3, a2, b2, ops, c, pa0, pa1, pb0, pb1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                     // the last tile's reduction
+        const int i = 96 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float2 v = *reinterpret_cast<const float2*>(lds + L_V4 + 4 * i + 1);
+        const float qa = __builtin_fmaxf(a3[r], 0.0f), qb = __builtin_fmaxf(b3[r], 0.0f);
+        pa0 = __builtin_fmaf(v.x, qa, pa0);
+        pa1 = __builtin_fmaf(v.y, qa, pa1);
+        pb0 = __builtin_fmaf(v.x, qb, pb0);
+        pb1 = __builtin_fmaf(v.y, qb, pb1);
+    }
+    const float qa0 = __shfl_xor(pa0, 32, 64), qa1 = __shfl_xor(pa1, 32, 64);
+    const float qb0 = __shfl_xor(pb0, 32, 64), qb1 = __shfl_xor(pb1, 32, 64);
+    const float b30 = lds[L_B3 + 0], b31 = lds[L_B3 + 1];
+    shift_a = ((half ? qa0 : pa0) + (half ? pa0 : qa0)) + b30;
+    log_s_a = ((half ? qa1 : pa1) + (half ? pa1 : qa1)) + b31;
+    shift_b = ((half ? qb0 : pb0) + (half ? pb0 : qb0)) + b30;
+    log_s_b = ((half ? qb1 : pb1) + (half ? pb1 : qb1)) + b31;
+}
+
 // One row tile per wavefront: the form for small inputs (at most one tile per CU), where the launch is a latency chain
 // and half the MFMAs per coupling beat operand reuse.  Same arithmetic per row as coupling_params2.
 __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, float z0, int lane, float& shift, float& log_s)
@@ -402,17 +533,44 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
         }
     }
 
+    // A coupling's parameter block reaches LDS through registers, one coupling AHEAD: each work-item holds its six float4 of the
+    // NEXT block while the workgroup computes on the current one (the loads are issued right after the barrier that publishes the
+    // current block and have a whole coupling to arrive), so the boundary between two couplings costs two barriers and 67 KiB of
+    // ds_write instead of an L2 round trip with every wavefront idle.  (A second LDS image filled by LDS-DMA was tried in round 2:
+    // no faster then, and it takes the LDS a deeper pair queue needs.)
+    constexpr int W2_VEC = NF_H * NF_H / 4, BLOCK_VEC = NF_BLOCK_FLOATS / 4, SMALL_VEC = BLOCK_VEC - W2_VEC;
+    constexpr int PRE = (BLOCK_VEC + 64 * NF_WAVES - 1) / (64 * NF_WAVES);
+    static_assert(PRE <= 9, "prefetch registers");
+    float4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7, pre8;        // named, not an array: an array indexed in (unrolled) loops stayed in scratch
+    (void)pre6; (void)pre7; (void)pre8;
+#define GLABC_NF_PRE_ONE(J_, R_)                                                    \
+    if constexpr (PRE > J_) {                                                       \
+        const int i_ = (int)threadIdx.x + J_ * 64 * NF_WAVES;                       \
+        R_ = src_[i_ < BLOCK_VEC ? i_ : BLOCK_VEC - 1];                             \
+    }
+#define GLABC_NF_PREFETCH_BLOCK(C_)                                                                         \
+    {                                                                                                       \
+        const float4* src_ = reinterpret_cast<const float4*>(a.params + (int64_t)(C_) * NF_BLOCK_FLOATS);   \
+        GLABC_NF_PRE_ONE(0, pre0) GLABC_NF_PRE_ONE(1, pre1) GLABC_NF_PRE_ONE(2, pre2) GLABC_NF_PRE_ONE(3, pre3) GLABC_NF_PRE_ONE(4, pre4) \
+        GLABC_NF_PRE_ONE(5, pre5) GLABC_NF_PRE_ONE(6, pre6) GLABC_NF_PRE_ONE(7, pre7) GLABC_NF_PRE_ONE(8, pre8)                     \
+    }
+#define GLABC_NF_COMMIT_ONE(J_, R_)                                                                         \
+    if constexpr (PRE > J_) {                                                                               \
+        const int i_ = (int)threadIdx.x + J_ * 64 * NF_WAVES; /* global order: W2^T | W1 | b1 | V4 | b3; the LDS image has W2^T last */ \
+        if (i_ < BLOCK_VEC) dst_[i_ < W2_VEC ? L_W2 / 4 + i_ : i_ - W2_VEC] = R_;                           \
+    }
+    GLABC_NF_PREFETCH_BLOCK(INVERSE ? a.n_couplings - 1 : 0)
     for (int cc = 0; cc < a.n_couplings; ++cc) {
         const int c = INVERSE ? (a.n_couplings - 1 - cc) : cc;
         __syncthreads();                                               // everyone is done with the previous block
         {
-            const float4* src = reinterpret_cast<const float4*>(a.params + (int64_t)c * NF_BLOCK_FLOATS);
-            float4* dst = reinterpret_cast<float4*>(lds);
-            constexpr int W2_VEC = NF_H * NF_H / 4, SMALL_VEC = (NF_BLOCK_FLOATS - NF_H * NF_H) / 4;
-            for (int i = threadIdx.x; i < W2_VEC; i += 64 * NF_WAVES) dst[L_W2 / 4 + i] = src[i];              // W2^T
-            for (int i = threadIdx.x; i < SMALL_VEC; i += 64 * NF_WAVES) dst[i] = src[W2_VEC + i];             // W1 | b1 | V4 | b3
+            float4* dst_ = reinterpret_cast<float4*>(lds);
+            GLABC_NF_COMMIT_ONE(0, pre0) GLABC_NF_COMMIT_ONE(1, pre1) GLABC_NF_COMMIT_ONE(2, pre2) GLABC_NF_COMMIT_ONE(3, pre3)
+            GLABC_NF_COMMIT_ONE(4, pre4) GLABC_NF_COMMIT_ONE(5, pre5) GLABC_NF_COMMIT_ONE(6, pre6) GLABC_NF_COMMIT_ONE(7, pre7)
+            GLABC_NF_COMMIT_ONE(8, pre8)
         }
         __syncthreads();
+        if (cc + 1 < a.n_couplings) GLABC_NF_PREFETCH_BLOCK(INVERSE ? c - 1 : c + 1)
         if constexpr (TILE_MODE) {
             if (tile_active) {
                 float sh, ls;
@@ -424,14 +582,24 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
                 nf_row_apply<INVERSE>(sh, ls, z0, z1, lq);
             }
         } else {
+#if GLABC_NF_FORM == 2
+            NfOps ops;                                                 // group 0 of tile 0 and its b2: fetched once per coupling,
+            f32x16 cinit;                                              // handed from pair to pair (coupling_params2_ahead)
+            if (p_first < n_pairs) {
+                nf_fetch_ops(lds, lane >> 5, col, 0, 0, ops);
+                nf_fetch_bias(lds, lane >> 5, 0, cinit);
+            }
+#endif
             for (int p = p_first; p < n_pairs; p += p_stride) {
                 float* s = st + p * 192 + col;                         // both lanes of a row read the same words
                 float a0 = s[0], a1 = s[32], al = s[64], b0 = s[96], b1 = s[128], bl = s[160];
                 float sa, la, sb, lb;
-#ifdef GLABC_NF_K_OUTER        // the round-2 form (k outermost, all four tiles' accumulators alive): an A/B knob
+#if GLABC_NF_FORM == 0         // the round-2 form (k outermost, all four tiles' accumulators alive): an A/B knob
                 coupling_params2(lds, INVERSE ? a1 : a0, INVERSE ? b1 : b0, lane, sa, la, sb, lb);
-#else
+#elif GLABC_NF_FORM == 1       // output tile outermost, operand fetch left to the compiler (round 3a)
                 coupling_params2_tile_outer(lds, INVERSE ? a1 : a0, INVERSE ? b1 : b0, lane, sa, la, sb, lb);
+#else
+                coupling_params2_ahead(lds, INVERSE ? a1 : a0, INVERSE ? b1 : b0, lane, ops, cinit, sa, la, sb, lb);
 #endif
                 if (INVERSE && a.trace) {                              // lane l: row 64 p + l of the pair (tile a | tile b)
                     const int64_t row = wg_row0 + (int64_t)p * 64 + lane;

@@ -40,10 +40,11 @@ def GLMALA(ABCset, num_ite, Initial_theta, Initial_y, tau, num_grad,
     dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
     chains.add_mala_state()
     hist = _host.allocate_history(num_ite, chains, record_history)
+    mirror = _host.HostMirror(hist) if _host.HostMirror.wanted(hist, single, return_device) else None   # rows leave for the host while the kernels run
     engine.glmala_init(model, chains)                                  # GLMALA.py:143-149
     engine.run_glmala_steps(model, imp, mala, chains, num_ite - 1, 1, engine.draw_seed(seed), global_frequency,
                             batch_size, history=None if hist is None else hist[1:], moments=stats,
-                            steps_per_launch=steps_per_launch)
+                            steps_per_launch=steps_per_launch, mirror=mirror)
     if state_out is not None:
         state_out["chains"] = chains
-    return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)
+    return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device, mirror=mirror)

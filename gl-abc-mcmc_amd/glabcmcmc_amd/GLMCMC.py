@@ -48,6 +48,7 @@ def GLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
     imp = Importance_Proposal.descriptor()
     dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
     hist = _host.allocate_history(num_ite, chains, record_history)
+    mirror = _host.HostMirror(hist) if _host.HostMirror.wanted(hist, single, return_device) else None   # rows leave for the host while the kernels run
     rtc = None
     if model.sim_kind == _capi.SIM_USER:                           # compiled.CompiledModel: the simulator is run-time compiled C
         rtc = ABCset.program(_capi.ALGO_GLMCMC, batch_size)       # (log_weight_old is computed at the first global move: `local` starts set)
@@ -55,8 +56,8 @@ def GLMCMC(ABCset, num_ite, Initial_theta, Initial_y, Local_Proposal,
         engine.init_weights(model, imp, chains)                    # GLMCMC.py:52-55
     engine.run_steps("glabc_glmcmc_steps", model, local, imp, chains, num_ite - 1, 1, engine.draw_seed(seed),
                      global_frequency, batch_size, history=None if hist is None else hist[1:], moments=stats,
-                     steps_per_launch=steps_per_launch, rtc_program=rtc,
+                     steps_per_launch=steps_per_launch, rtc_program=rtc, mirror=mirror,
                      math_mode=_capi.MATH_FAST if fast_math else _capi.MATH_EXACT)
     if state_out is not None:
         state_out["chains"] = chains
-    return _host.finish(hist, chains, single, filelocation, "glmcmc", verbose and single, return_device)
+    return _host.finish(hist, chains, single, filelocation, "glmcmc", verbose and single, return_device, mirror=mirror)

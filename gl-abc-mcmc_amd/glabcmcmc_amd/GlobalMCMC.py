@@ -27,10 +27,11 @@ def GlobalMCMC(ABCset, num_ite, Initial_theta, Initial_y,
     glob = Global_Proposal.descriptor()
     dev, chains, single = _host.prepare(ABCset, Initial_theta, Initial_y, device, chain0)
     hist = _host.allocate_history(num_ite, chains, record_history)
+    mirror = _host.HostMirror(hist) if _host.HostMirror.wanted(hist, single, return_device) else None   # rows leave for the host while the kernels run
     rtc = ABCset.program(_capi.ALGO_GLOBALMCMC) if model.sim_kind == _capi.SIM_USER else None     # compiled.CompiledModel
     engine.run_steps("glabc_globalmcmc_steps", model, local, glob, chains, num_ite - 1, 1, engine.draw_seed(seed),
                      global_frequency, 1, history=None if hist is None else hist[1:], moments=stats,
-                     steps_per_launch=steps_per_launch, rtc_program=rtc)
+                     steps_per_launch=steps_per_launch, rtc_program=rtc, mirror=mirror)
     if state_out is not None:
         state_out["chains"] = chains
-    return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device)
+    return _host.finish(hist, chains, single, filelocation, "global", verbose and single, return_device, mirror=mirror)

@@ -26,10 +26,57 @@ def allocate_history(num_ite, chains, record_history):
     return hist
 
 
-def finish(hist, chains, single, filelocation, csv_variant, verbose, return_device):
+class HostMirror:
+    """Theta_Re on its way to host memory WHILE the sampler runs (the reference returns a CPU tensor, GLMCMC.py:137).  A large
+    history leaves the device at PCIe speed (57 GB/s into pinned memory) -- several times the time the
+    kernels need to produce it -- so the copy must not wait for the end of the run: after every launch its rows go to a pinned
+    buffer on a second stream while the next launch computes.  The fused wrappers use it by default for histories of 16 MiB and
+    more that are returned to the host (many chains); engine.run_steps / run_glmala_steps call rows_done()."""
+    MIN_ELEMS = 1 << 22
+    LAUNCH_BYTES = 64 << 20                                        # rows per launch: about this much history, so that copies and
+                                                                   # kernels alternate often enough to overlap
+    def __init__(self, hist):
+        self.hist = hist                                           # [num_ite][d][C] on the device
+        self.host = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
+        self.stream = torch.cuda.Stream(hist.device)
+        self.rows = 0                                              # rows already handed to the copy stream
+        self.rows_done(1)                                          # row 0 = Initial_theta
+
+    @staticmethod
+    def wanted(hist, single, return_device):
+        return hist is not None and not single and not return_device and hist.numel() >= HostMirror.MIN_ELEMS
+
+    def steps_per_launch(self, requested):
+        if requested:
+            return requested
+        return max(8, self.LAUNCH_BYTES // (4 * self.hist.shape[1] * self.hist.shape[2]))
+
+    def rows_done(self, upto):
+        """rows [self.rows, upto) of the history have been enqueued on the current stream: copy them behind it"""
+        if upto <= self.rows:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.hist.device))
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            self.host[self.rows:upto].copy_(self.hist[self.rows:upto], non_blocking=True)
+        self.rows = upto
+
+    def result(self):
+        self.rows_done(self.hist.shape[0])
+        self.stream.synchronize()
+        return self.host
+
+
+def finish(hist, chains, single, filelocation, csv_variant, verbose, return_device, mirror=None):
     """What the reference does after its loop: CSV rows, summary print, return Theta_Re."""
     if hist is None:
         return None
+    if mirror is not None:                                         # the rows are (almost) in host memory already
+        host = mirror.result().permute(0, 2, 1)                    # (num_ite, C, d) view of the chain-major host buffer
+        if filelocation is not None:
+            write_csv(host.reshape(host.shape[0], -1), filelocation, csv_variant)
+        return host
     if single:
         Theta_Re = hist[:, :, 0].cpu()                             # (num_ite, d) float32 CPU, as the reference returns
         if filelocation is not None:

@@ -133,7 +133,7 @@ class Moments:
 
 def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0, seed, global_frequency, batch_size,
               history=None, moments=None, steps_per_launch=None, lanes_per_chain=0, debug_flags=0, gf_per_chain=None,
-              rtc_program=None, math_mode=0, dump_draws=None):
+              rtc_program=None, math_mode=0, dump_draws=None, mirror=None):
     """Advance `chains` by n_steps iterations with the C-ABI entry point `entry`
     ('glabc_glmcmc_steps' / 'glabc_globalmcmc_steps'), K iterations per launch.
 
@@ -147,6 +147,8 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
     (glabc_glmcmc_steps only, opt-in: hardware transcendentals -- the same law from another stream of normals, include/glabc.h).
     dump_draws: MATH_FAST only -- (u [C][n_steps][2] float32, r [C][n_steps] float64, z [C][n_steps][N][d + y_dim] float32) device
     tensors that receive the draws the kernel used, in the layout of glabc_tape (one launch: steps_per_launch >= n_steps).
+    mirror: None or the _host.HostMirror of the tensor `history` is rows 1.. of: every launch's rows are copied to pinned host
+    memory on a second stream while the next launch runs (launches are then cut to mirror.steps_per_launch rows).
     """
     lib = _capi.lib()
     if rtc_program is not None:
@@ -157,6 +159,8 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
     else:
         fn = getattr(lib, entry)
     k_max = int(steps_per_launch or MAX_STEPS_PER_LAUNCH)
+    if mirror is not None:
+        k_max = min(k_max, int(mirror.steps_per_launch(steps_per_launch)))
     cs = chains.struct()
     ms = moments.struct() if moments is not None else None
     stream = torch.cuda.current_stream(chains.device).cuda_stream
@@ -188,6 +192,8 @@ def run_steps(entry, model_desc, local_desc, global_desc, chains, n_steps, step0
             _capi.check(fn(C.byref(model_desc), C.byref(local_desc), C.byref(global_desc), C.byref(cs), C.byref(run),
                            C.c_void_p(stream)), entry)
             done += k
+            if mirror is not None:
+                mirror.rows_done(step0 + done)                     # history row i = iteration i (row 0 = Initial_theta)
     if moments is not None:
         moments.steps += n_steps
 
@@ -201,12 +207,14 @@ def glmala_init(model_desc, chains):
 
 
 def run_glmala_steps(model_desc, importance_desc, mala, chains, n_steps, step0, seed, global_frequency, batch_size,
-                     history=None, moments=None, steps_per_launch=None, lanes_per_chain=0):
+                     history=None, moments=None, steps_per_launch=None, lanes_per_chain=0, mirror=None):
     """GLMALA twin of run_steps (entry point glabc_glmala_steps); `mala` is a _capi.Mala.
     lanes_per_chain: 0 = let the library choose; 1 = 64 chains per wavefront, 2 = 32 (the other 32 lanes only help with the
     wave-cooperative gradient) -- launch geometry, results are identical."""
     lib = _capi.lib()
     k_max = int(steps_per_launch or MAX_STEPS_PER_LAUNCH)
+    if mirror is not None:
+        k_max = min(k_max, int(mirror.steps_per_launch(steps_per_launch)))
     cs = chains.struct()
     ms = moments.struct() if moments is not None else None
     stream = torch.cuda.current_stream(chains.device).cuda_stream
@@ -229,6 +237,8 @@ def run_glmala_steps(model_desc, importance_desc, mala, chains, n_steps, step0, 
             _capi.check(lib.glabc_glmala_steps(C.byref(model_desc), C.byref(importance_desc), C.byref(mala), C.byref(cs),
                                                C.byref(run), C.c_void_p(stream)), "glabc_glmala_steps")
             done += k
+            if mirror is not None:
+                mirror.rows_done(step0 + done)
     if moments is not None:
         moments.steps += n_steps
 

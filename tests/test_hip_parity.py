@@ -1173,6 +1173,53 @@ def test_gamma_descriptor_entry_points(hip, oracle):
     torch.cuda.synchronize()
 
 
+# ---------------------------------------------------------------------------------- the drop-in return path
+@pytest.mark.parametrize("sampler", ["glmcmc", "globalmcmc", "glmala"])
+def test_large_histories_reach_the_host_while_the_kernels_run(hip, sampler, monkeypatch, tmp_path):
+    """The reference returns Theta_Re as a CPU tensor (GLMCMC.py:137).  A history of 16 MiB and more of many chains is copied to
+    pinned host memory launch by launch on a second stream WHILE the next launch computes (_host.HostMirror) instead of after the
+    run: same rows, bit for bit, as the device-resident history of the same seed -- also when the run is cut into many short
+    launches -- and the CSV file written from it equals the one written from the device copy."""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import _host, distribution
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    n, T = 4096, 520                                                    # 521 x 2 x 4096 floats = 16.3 MiB
+    gen = torch.Generator().manual_seed(3)
+    theta0 = torch.randn(n, 2, generator=gen)
+    y0 = theta0.abs() + (0.05 ** 0.5) * torch.randn(n, 2, generator=gen)
+    lp = distribution.DiagGaussian(2, torch.zeros(2), torch.log(torch.tensor([0.35, 0.35])))
+    ip = distribution.DiagGaussian(2, torch.zeros(2), torch.zeros(2))
+    model = Mixture_set(0.05)
+
+    def run(**kw):
+        if sampler == "glmcmc":
+            return g_.GLMCMC(model, T + 1, theta0, y0, lp, kw.pop("file", None), 0.9, ip, 5, seed=11, verbose=False, **kw)
+        if sampler == "globalmcmc":
+            return g_.GlobalMCMC(model, T + 1, theta0, y0, ip, kw.pop("file", None), 0.5, lp, seed=11, verbose=False, **kw)
+        return g_.GLMALA(model, T + 1, theta0, y0, 0.3, 20, kw.pop("file", None), 0.8, ip, 5, seed=11, verbose=False, **kw)
+
+    made = []
+    real = _host.HostMirror.__init__
+
+    def spy(self, hist):
+        made.append(self)
+        real(self, hist)
+
+    monkeypatch.setattr(_host.HostMirror, "__init__", spy)
+    want = run(return_device=True)                                      # (T+1, n, 2) view of the device history
+    assert not made and want.is_cuda
+    got = run()
+    assert len(made) == 1 and not got.is_cuda and got.shape == want.shape
+    assert np.array_equal(bits(got.numpy()), bits(want.cpu().numpy()))
+    monkeypatch.setattr(_host.HostMirror, "LAUNCH_BYTES", 1 << 20)      # 32 rows per launch: 17 launches, 17 copies behind them
+    f1, f2 = str(tmp_path / "a.csv"), str(tmp_path / "b.csv")
+    got2 = run(file=f1)
+    assert len(made) == 2 and np.array_equal(bits(got2.numpy()), bits(want.cpu().numpy()))
+    if sampler == "glmcmc":
+        run(file=f2, return_device=True)
+        assert open(f1, "rb").read() == open(f2, "rb").read()
+
+
 # ---------------------------------------------------------------------------------- BASELINE configs[0], literally
 def test_config_1_runner_global_mcmc_one_chain_10000_iterations(hip, oracle, tmp_path, capsys):
     """BASELINE.json configs[0]: Mixture_set eps 0.05, dim 2, ONE chain x 10 000 iterations through MCMCRunner.run_global_mcmc
