@@ -356,14 +356,6 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
     float gw3acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // dW3[col >> 4][unit (col & 15) of tile t, this half], this wave's tiles
     float gw1a[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gb1a[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // unit 32 t + col, this wave's tiles
     float gb30 = 0.0f, gb31 = 0.0f;               // this lane's rows
-    float w1c[4], b1c[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        w1c[t] = lds[C_W1 + 32 * t + col];
-        b1c[t] = lds[C_B1 + 32 * t + col];
-    }
-    const float w30i = lds[C_W30 + 32 * iblk + col], w31i = lds[C_W31 + 32 * iblk + col];
-    const float b31 = lds[C_B3 + 1];
 
     const int64_t wg_row0 = (int64_t)blockIdx.x * a.rows_per_wg;
     // the rows of a tile are loaded one batch ahead (issued before phase 2, consumed after the next barrier pair)
@@ -424,7 +416,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
         head(a1, 1);
         head(a2, 2);
         head(a3, 3);
-        const float log_s = (p1 + __shfl_xor(p1, 32, 64)) + b31;
+        const float log_s = (p1 + __shfl_xor(p1, 32, 64)) + lds[C_B3 + 1];
         const float dz1 = g1p * glabc_expf_b(-log_s);
         const float dsh = -dz1;
         const float dls = -(g1p * z1p) - gl_row;
@@ -491,18 +483,23 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
             back(a1, 1);
             back(a2, 2);
             back(a3, 3);
+            // W1 / b1 of this pass's two 32-unit tiles, read here rather than held in eight registers through all three phases
+            // (the kernel is at its 256-register budget: 16 registers used to be spilled)
+            const float w1c[2] = {lds[C_W1 + 64 * pass + col], lds[C_W1 + 64 * pass + 32 + col]};
+            const float b1c[2] = {lds[C_B1 + 64 * pass + col], lds[C_B1 + 64 * pass + 32 + col]};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const float zr = __shfl(z0, m, 64);
-                auto unit = [&](float dh1, int t) {
-                    const float da1 = __builtin_fmaf(w1c[t], zr, b1c[t]) > 0.0f ? dh1 : 0.0f;
+                auto unit = [&](float dh1, int u) {
+                    const int t = 2 * pass + u;
+                    const float da1 = __builtin_fmaf(w1c[u], zr, b1c[u]) > 0.0f ? dh1 : 0.0f;
                     gw1a[t] = __builtin_fmaf(da1, zr, gw1a[t]);
                     gb1a[t] += da1;
-                    part[r] = __builtin_fmaf(w1c[t], da1, part[r]);
+                    part[r] = __builtin_fmaf(w1c[u], da1, part[r]);
                 };
-                unit(d0[r], 2 * pass);
-                unit(d1[r], 2 * pass + 1);
+                unit(d0[r], 0);
+                unit(d1[r], 1);
             }
         }
         float mine = 0.0f;
@@ -528,6 +525,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
             const float* zs = lds + C_Z0 + half;
             const float* ds = lds + C_DSH + half;
             const float* dl = lds + C_DLS + half;
+            const float w30i = lds[C_W30 + 32 * iblk + col], w31i = lds[C_W31 + 32 * iblk + col];   // (read per batch: registers)
             float w1p[NACC], b1p[NACC];                              // this wave's input units 32 (NACC kpart + t) + col
 #pragma unroll
             for (int t = 0; t < NACC; ++t) {
@@ -535,13 +533,15 @@ __global__ void __launch_bounds__(64 * WAVES, 2) nf_backward_kernel2(const BwArg
                 b1p[t] = lds[C_B1 + 32 * (NACC * kpart + t) + col];
             }
             for (int tile = 0; tile < WAVES; ++tile) {               // rows 32 tile .. of the batch: wave `tile`'s sign bits
-                const uint32_t mw = mask[(32 * iblk + col) * WAVES + tile];
+                // this half's sign bits moved to the even positions once per tile: the bit tests below then use immediate masks (with
+                // `mw >> (2 ss + half)` the compiler kept the sixteen lane-dependent masks 1 << (2 ss + half) in registers)
+                const uint32_t mw = mask[(32 * iblk + col) * WAVES + tile] >> half;
 #pragma unroll
                 for (int ss = 0; ss < 16; ++ss) {
                     const int s = 16 * tile + ss;                    // row 2 s + half = 32 tile + (2 ss + half)
                     const float dsr = ds[2 * s], dlr = dl[2 * s], zr = zs[2 * s];
                     const float dh2 = __builtin_fmaf(w30i, dsr, w31i * dlr);
-                    const float da2 = ((mw >> (2 * ss + half)) & 1u) ? dh2 : 0.0f;
+                    const float da2 = ((mw >> (2 * ss)) & 1u) ? dh2 : 0.0f;
                     gb2 += da2;
 #pragma unroll
                     for (int t = 0; t < NACC; ++t)
