@@ -449,9 +449,48 @@ GLABC_DEV void model_simulate(const StepArgs<D, YD>& a, const float (&theta)[D],
 // LEAN_SQRT: the caller knows every |y_obs_j| >= 2^-6, so a difference y_j - y_obs_j is 0 or at least 2^-31 in
 // magnitude and the sum of squares is 0 or >= 2^-62 -- the domain on which glabc_sqrtf_normal is the correctly
 // rounded square root (8 instructions less than the general expansion, five times per step)
+// Run-time compiled builds (glabc_rtc.hip) may replace each of the Model's other callbacks as well: the user's source announces
+//   #define GLABC_USER_PRIOR 1        float glabc_user_prior_log_prob(const float* theta)                 Mixture.py:28-31
+//   #define GLABC_USER_DISCREPANCY 1  float glabc_user_discrepancy(const float* y, const float* y_obs)    Mixture.py:33-36
+//   #define GLABC_USER_KERNEL 1       float glabc_user_log_kernel(float dis, float scale)                 Mixture.py:38-45
+// (scale = the float32 kernel width of the descriptor, exp(log(epsilon))); whatever is not announced stays the descriptor's.
+template <int YD>
+GLABC_DEV float model_discrepancy_rows(const float (&y)[YD], const float* y_obs)
+{
+#ifdef GLABC_USER_DISCREPANCY
+    float yo[YD];
+#pragma unroll
+    for (int j = 0; j < YD; ++j) yo[j] = y_obs[j];
+    return glabc_user_discrepancy(y, yo);
+#else
+    float t[YD];
+#pragma unroll
+    for (int j = 0; j < YD; ++j) {
+        float d = y[j] - y_obs[j];
+        t[j] = d * d;
+    }
+    return __builtin_sqrtf(aten_rowsum<YD>(t));
+#endif
+}
+
+GLABC_DEV float model_log_kernel_of(float dis, float kern_scale, float kern_log_scale, float kern_c0)
+{
+#ifdef GLABC_USER_KERNEL
+    (void)kern_log_scale;
+    (void)kern_c0;
+    return glabc_user_log_kernel(dis, kern_scale);
+#else
+    const float e = (dis - 0.0f) / kern_scale;
+    return kern_c0 - (kern_log_scale + 0.5f * (e * e));
+#endif
+}
+
 template <int D, int YD, bool LEAN_SQRT = false, bool FAST = false>
 GLABC_DEV float model_log_kernel(const StepArgs<D, YD>& a, const float (&y)[YD])
 {
+#if defined(GLABC_USER_DISCREPANCY) || defined(GLABC_USER_KERNEL)
+    return model_log_kernel_of(model_discrepancy_rows<YD>(y, a.y_obs), a.kern_scale, a.kern_log_scale, a.kern_c0);
+#else
     float t[YD];
 #pragma unroll
     for (int j = 0; j < YD; ++j) {
@@ -477,6 +516,17 @@ GLABC_DEV float model_log_kernel(const StepArgs<D, YD>& a, const float (&y)[YD])
         e = (dis - 0.0f) / a.kern_scale;
     }
     return a.kern_c0 - (a.kern_log_scale + 0.5f * (e * e));
+#endif
+}
+
+template <int D, int YD, bool GU, bool GM>
+GLABC_DEV float model_prior(const StepArgs<D, YD>& a, const float (&theta)[D])
+{
+#ifdef GLABC_USER_PRIOR
+    return glabc_user_prior_log_prob(theta);
+#else
+    return dist_log_prob<D, GU, GM>(a.prior, theta);
+#endif
 }
 
 // ---- random draws of one (chain, step) ---------------------------------------------
@@ -579,7 +629,7 @@ struct Chain {
 template <int D, int YD, bool GAMMA_OK = false>
 GLABC_DEV void refresh_cache(const StepArgs<D, YD>& a, Chain<D, YD>& c)
 {
-    c.prior = dist_log_prob<D, false, GAMMA_OK>(a.prior, c.theta);
+    c.prior = model_prior<D, YD, false, GAMMA_OK>(a, c.theta);
     c.kern = model_log_kernel<D, YD>(a, c.y);
     c.q = dist_log_prob<D, false, GAMMA_OK>(a.global, c.theta);
 }
@@ -728,7 +778,7 @@ GLABC_DEV bool chain_step(const StepArgs<D, YD>& a, const Rng& rng, uint32_t ste
             lq = g_gam ? lq_gamma : dist_forward_log_p<D, GU>(a.global, e);   // unused by the local move
         }
         model_simulate<D, YD>(a, th[r], s, yy[r]);
-        pr[r] = dist_log_prob<D, GU, GM>(a.prior, th[r]);
+        pr[r] = model_prior<D, YD, GU, GM>(a, th[r]);
         kk[r] = model_log_kernel<D, YD, GU>(a, yy[r]);
         const float pk = pr[r] + kk[r];
         lw[r] = pk - lq;                                                      // GLMCMC.py:74

@@ -21,7 +21,8 @@ SIM_ABS_GAUSS = 0
 SIM_GK = 1
 SIM_USER = 2
 
-VERSION = 300                  # include/glabc.h GLABC_VERSION
+RTC_PRIOR_LOG_PROB, RTC_DISCREPANCY, RTC_LOG_KERNEL = 0, 1, 2      # glabc_rtc_model_rows `what`
+VERSION = 301                  # include/glabc.h GLABC_VERSION
 STREAM_LAYOUT = 2              # include/glabc.h GLABC_STREAM_LAYOUT
 
 FLAG_LOCAL = 1
@@ -270,6 +271,8 @@ ENTRY_POINTS = {
     "glabc_rtc_steps": (C.c_int, [C.c_void_p, _P(Model), _P(Dist), _P(Dist), _P(Chains), _P(Run), C.c_void_p]),
     "glabc_rtc_simulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_rtc_release": (None, [C.c_void_p]),
+    "glabc_rtc_hooks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "glabc_rtc_model_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glabc_propose": (C.c_int, [C.c_int, _P(Dist), _P(Dist), _P(Chains), _P(Run), _P(StepIO), C.c_void_p]),
     "glabc_propose_redraw": (C.c_int, [_P(Dist), _P(Chains), _P(Run), _P(StepIO), C.c_int32, C.c_void_p, C.c_void_p]),
     "glabc_select": (C.c_int, [C.c_int, _P(Dist), _P(Chains), _P(Run), _P(StepIO), C.c_void_p]),

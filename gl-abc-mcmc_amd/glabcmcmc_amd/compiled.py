@@ -15,8 +15,19 @@ If the simulator can be written as a few lines of C, ``CompiledModel`` compiles 
                           y_obs=[1.5, 1.5], epsilon=0.05)
     MCMCRunner(model).run_glmcmc(...)
 
-The rest of the Model is what the reference's example uses: a ``DiagGaussian`` / ``Uniform`` prior, the Euclidean
-discrepancy to ``y_obs`` and the Gaussian ABC kernel of width ``epsilon`` (examples/Mixture.py:28-45).  The object also
+The rest of the Model defaults to what the reference's example uses: a ``DiagGaussian`` / ``Uniform`` prior, the Euclidean
+discrepancy to ``y_obs`` and the Gaussian ABC kernel of width ``epsilon`` (examples/Mixture.py:28-45) -- and each of them can be
+user source too: the same string may define, announced by a ``#define`` each,
+
+    #define GLABC_USER_PRIOR 1
+    GLABC_SIMULATOR float glabc_user_prior_log_prob(const float* theta) { ... }               /* Mixture.py:28-31 */
+    #define GLABC_USER_DISCREPANCY 1
+    GLABC_SIMULATOR float glabc_user_discrepancy(const float* y, const float* y_obs) { ... }  /* Mixture.py:33-36 */
+    #define GLABC_USER_KERNEL 1
+    GLABC_SIMULATOR float glabc_user_log_kernel(float dis, float scale) { ... }               /* Mixture.py:38-45 */
+
+which the fused kernel then calls in place of the descriptor's forms (``prior`` stays a required argument: with a user prior it
+only says where the self-check starts its chains).  The object also
 implements the full duck-typed protocol (``generate_samples`` through the compiled simulator on rows, ``prior_log_prob`` /
 ``discrepancy`` / ``calculate_log_kernel`` through the row-wise kernels), so it works with every sampler, the split-phase
 path included.  Use + - * / fmaf sqrtf fabsf and the ``glabc_*`` functions of include/glabc_numerics.h (``glabc_expf``,
@@ -53,6 +64,12 @@ class CompiledModel:
         self._programs = {}
         self._checked = set()
         self._failed = {}                                 # (algorithm, batch size) -> message of the failed self-check
+        self.user_prior, self.user_discrepancy, self.user_kernel = (self._announces(m) for m in
+                                                                    ("GLABC_USER_PRIOR", "GLABC_USER_DISCREPANCY", "GLABC_USER_KERNEL"))
+
+    def _announces(self, macro):
+        import re
+        return re.search(r"define[ \t]+%s(?![A-Za-z0-9_])" % macro, self.simulator_source) is not None
 
     # ---- run-time compiled programs, one per (algorithm, batch size) -------------------------------------------------
     def program(self, algo, batch_size=1):
@@ -154,19 +171,39 @@ class CompiledModel:
     def _dev(self, t):
         return t if t.is_cuda else t.to(engine.require_device(None))
 
+    def _rows(self, what, rows, epsilon=None):
+        """glabc_rtc_model_rows: a callback the source replaces, on rows, through the functions the fused kernel calls"""
+        x = self._dev(rows).detach().to(torch.float32).contiguous()
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        m = self.descriptor(epsilon)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            _capi.check(_capi.lib().glabc_rtc_model_rows(self.program(_capi.ALGO_GLOBALMCMC), C.byref(m), what, x.data_ptr(),
+                                                         x.shape[0], out.data_ptr(), C.c_void_p(stream)), "glabc_rtc_model_rows")
+        return out
+
     def prior_log_prob(self, samples):
         s = samples.reshape(-1, self.theta_dim)
-        out = _launch_rowwise("glabc_model_prior_log_prob", self.descriptor(), self._dev(s), "prior_log_prob")
+        if self.user_prior:
+            out = self._rows(_capi.RTC_PRIOR_LOG_PROB, s)
+        else:
+            out = _launch_rowwise("glabc_model_prior_log_prob", self.descriptor(), self._dev(s), "prior_log_prob")
         return out if samples.is_cuda else out.cpu()
 
     def discrepancy(self, y):
         yy = y.reshape(-1, self.y_dim)
-        out = _launch_rowwise("glabc_model_discrepancy", self.descriptor(), self._dev(yy), "discrepancy")
+        if self.user_discrepancy:
+            out = self._rows(_capi.RTC_DISCREPANCY, yy)
+        else:
+            out = _launch_rowwise("glabc_model_discrepancy", self.descriptor(), self._dev(yy), "discrepancy")
         return out if y.is_cuda else out.cpu()
 
     def calculate_log_kernel(self, y, epsilon=None):
         yy = y.reshape(-1, self.y_dim)
-        out = _launch_rowwise("glabc_model_log_kernel", self.descriptor(epsilon), self._dev(yy), "calculate_log_kernel")
+        if self.user_discrepancy or self.user_kernel:
+            out = self._rows(_capi.RTC_LOG_KERNEL, yy, epsilon)
+        else:
+            out = _launch_rowwise("glabc_model_log_kernel", self.descriptor(epsilon), self._dev(yy), "calculate_log_kernel")
         return out if y.is_cuda else out.cpu()
 
     def descriptor(self, epsilon=None):

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GLABC_VERSION 300          /* 0.3.0: bumped whenever a struct of this header changes (the Python binding refuses a library
+#define GLABC_VERSION 301          /* 0.3.1: bumped whenever a struct of this header changes (the Python binding refuses a library
                                       of another version: a stale .so would misread the argument blocks) */
 /* Layout of the random stream (include/glabc_numerics.h): which Philox (counter, slot, word) a draw of (chain, iteration) reads.
  * A checkpoint stores it; resuming on another layout would continue on a different stream.  2 = simulator normals start at an
@@ -463,6 +463,27 @@ int glabc_rtc_steps(const glabc_rtc_program* program, const glabc_model* model, 
 /* generate_samples(theta, 1) of the compiled simulator on n row-major points: theta[n][theta_dim], eps[n][noise_dim] -> y[n][y_dim] */
 int glabc_rtc_simulate(const glabc_rtc_program* program, const float* theta, const float* eps, int64_t n, float* y, void* stream);
 void glabc_rtc_release(glabc_rtc_program* program);
+
+/* The Model's OTHER callbacks as user source (examples/Mixture.py:28-45 are Python methods too).  The same source string may
+ * define, each announced by a #define in that source, any of
+ *     #define GLABC_USER_PRIOR 1
+ *     GLABC_SIMULATOR float glabc_user_prior_log_prob(const float* theta)               // prior_log_prob, Mixture.py:28-31
+ *     #define GLABC_USER_DISCREPANCY 1
+ *     GLABC_SIMULATOR float glabc_user_discrepancy(const float* y, const float* y_obs)  // discrepancy, Mixture.py:33-36
+ *     #define GLABC_USER_KERNEL 1
+ *     GLABC_SIMULATOR float glabc_user_log_kernel(float dis, float scale)               // calculate_log_kernel of a discrepancy,
+ *                                                                                      // Mixture.py:38-45; scale = model->kern_scale
+ * and the fused kernel calls them where it would evaluate the descriptor's prior / Euclidean discrepancy / Gaussian kernel
+ * (a callback that is not announced stays the descriptor's; model->prior must still be a valid placeholder).  glabc_rtc_hooks
+ * reports what a program replaces; glabc_rtc_model_rows evaluates prior_log_prob (user priors only: descriptor priors have
+ * glabc_model_prior_log_prob), discrepancy or calculate_log_kernel on n row-major points through the very functions the fused
+ * kernel calls: in[n][theta_dim] or in[n][y_dim] -> out[n]. */
+#define GLABC_RTC_PRIOR_LOG_PROB 0
+#define GLABC_RTC_DISCREPANCY 1
+#define GLABC_RTC_LOG_KERNEL 2
+int glabc_rtc_hooks(const glabc_rtc_program* program, int32_t* user_prior, int32_t* user_discrepancy, int32_t* user_kernel);
+int glabc_rtc_model_rows(const glabc_rtc_program* program, const glabc_model* model, int32_t what, const float* in, int64_t n,
+                         float* out, void* stream);
 
 /* generate_samples(theta, 1) of a descriptor Model on n row-major points (Mixture.py:13-26 regime n x 1):
  * theta[n][theta_dim], eps[n][y_dim] standard normals (NULL: drawn from Philox(seed; row0 + r, 0, b), pairs of words)

@@ -326,6 +326,21 @@ static float gk_tanhf(float x)
 typedef void (*oracle_user_sim_fn)(const float* theta, const float* eps, float* y);
 static oracle_user_sim_fn g_user_sim = NULL;
 ORACLE_API void oracle_set_user_simulator(oracle_user_sim_fn fn) { g_user_sim = fn; }
+/* ... and the Model's other callbacks as user source (include/glabc.h, "The Model's OTHER callbacks as user source"): host builds
+ * of glabc_user_prior_log_prob / glabc_user_discrepancy / glabc_user_log_kernel, NULL = the descriptor's.  Used for
+ * sim_kind == GLABC_SIM_USER only. */
+typedef float (*oracle_user_prior_fn)(const float* theta);
+typedef float (*oracle_user_dis_fn)(const float* y, const float* y_obs);
+typedef float (*oracle_user_kern_fn)(float dis, float scale);
+static oracle_user_prior_fn g_user_prior = NULL;
+static oracle_user_dis_fn g_user_dis = NULL;
+static oracle_user_kern_fn g_user_kern = NULL;
+ORACLE_API void oracle_set_user_model(oracle_user_prior_fn prior, oracle_user_dis_fn dis, oracle_user_kern_fn kern)
+{
+    g_user_prior = prior;
+    g_user_dis = dis;
+    g_user_kern = kern;
+}
 
 /* standard normals one simulation consumes: y_dim for the built-in simulators, noise.dim for a user simulator */
 static int model_noise_dim(const glabc_model* m) { return m->sim_kind == GLABC_SIM_USER ? m->noise.dim : m->y_dim; }
@@ -360,6 +375,7 @@ static void model_simulate(const glabc_model* m, const float* theta, const float
 /* prior_log_prob, Mixture.py:28-31 */
 static float model_prior(const glabc_model* m, const float* theta)
 {
+    if (m->sim_kind == GLABC_SIM_USER && g_user_prior) return g_user_prior(theta);
     float v = 0.0f;
     dist_log_prob(&m->prior, theta, &v);
     return v;
@@ -368,6 +384,7 @@ static float model_prior(const glabc_model* m, const float* theta)
 /* discrepancy, Mixture.py:33-36: sqrt(sum_j (y_j - y_obs_j)^2) */
 static float model_discrepancy(const glabc_model* m, const float* y)
 {
+    if (m->sim_kind == GLABC_SIM_USER && g_user_dis) return g_user_dis(y, m->y_obs);
     float t[GLABC_MAX_DIM];
     for (int j = 0; j < m->y_dim; ++j) {
         float d = y[j] - m->y_obs[j];
@@ -379,6 +396,7 @@ static float model_discrepancy(const glabc_model* m, const float* y)
 /* calculate_log_kernel, Mixture.py:38-45: DiagGaussian(1, 0, log eps).log_prob(dis) */
 static float model_log_kernel_dis(const glabc_model* m, float dis)
 {
+    if (m->sim_kind == GLABC_SIM_USER && g_user_kern) return g_user_kern(dis, m->kern_scale);
     float e = (dis - 0.0f) / m->kern_scale;
     return m->kern_c0 - (m->kern_log_scale + 0.5f * (e * e));
 }

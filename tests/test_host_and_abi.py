@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), name
     h.glabc_version.restype = C.c_int
-    assert h.glabc_version() == 300 == _capi.VERSION and h.glabc_stream_layout() == _capi.STREAM_LAYOUT
+    assert h.glabc_version() == 301 == _capi.VERSION and h.glabc_stream_layout() == _capi.STREAM_LAYOUT
     h.glabc_status_string.restype = C.c_char_p
     assert h.glabc_status_string(0) == b"ok"
 

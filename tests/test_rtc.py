@@ -58,12 +58,61 @@ def host_simulator(source, d, yd, nd):
                 "#define GLABC_THETA_DIM %d\n#define GLABC_Y_DIM %d\n#define GLABC_NOISE_DIM %d\n#define GLABC_SIMULATOR static inline\n"
                 % (d, yd, nd) + source +
                 '\n__attribute__((visibility("default"))) void glabc_user_simulate_host(const float* t, const float* e, float* y)'
-                " { glabc_user_simulate(t, e, y); }\n")
+                " { glabc_user_simulate(t, e, y); }\n"
+                "#ifdef GLABC_USER_PRIOR\n"
+                '__attribute__((visibility("default"))) float glabc_user_prior_host(const float* t) { return glabc_user_prior_log_prob(t); }\n'
+                "#endif\n#ifdef GLABC_USER_DISCREPANCY\n"
+                '__attribute__((visibility("default"))) float glabc_user_dis_host(const float* y, const float* o) { return glabc_user_discrepancy(y, o); }\n'
+                "#endif\n#ifdef GLABC_USER_KERNEL\n"
+                '__attribute__((visibility("default"))) float glabc_user_kern_host(float d, float s) { return glabc_user_log_kernel(d, s); }\n'
+                "#endif\n")
     so = os.path.join(tmp, "sim.so")
     subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-ffp-contract=off", "-march=x86-64-v3", "-fno-math-errno",
                            "-I", os.path.join(ROOT, "include"), src, "-o", so, "-lm"])
     lib = C.CDLL(so)
+    for name, res, args in (("glabc_user_prior_host", C.c_float, [C.c_void_p]), ("glabc_user_dis_host", C.c_float, [C.c_void_p, C.c_void_p]),
+                            ("glabc_user_kern_host", C.c_float, [C.c_float, C.c_float])):
+        if hasattr(lib, name):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
     return lib, C.cast(lib.glabc_user_simulate_host, C.c_void_p)
+
+
+def host_hooks(lib):
+    """(prior, discrepancy, kernel) function pointers of a host_simulator library for oracle_set_user_model, NULL where the source
+    does not replace the callback"""
+    return tuple(C.cast(getattr(lib, n), C.c_void_p) if hasattr(lib, n) else None
+                 for n in ("glabc_user_prior_host", "glabc_user_dis_host", "glabc_user_kern_host"))
+
+
+# a Model whose EVERY callback is user source (examples/Mixture.py:13-45 are four Python methods): theta[2], eps[3] -> y[3]
+ALL_USER = """
+GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)
+{
+    y[0] = fabsf(theta[0]) + 0.3f * eps[0];
+    y[1] = theta[0] * theta[1] + 0.2f * eps[1];
+    y[2] = glabc_expf(-0.25f * (theta[1] * theta[1])) + 0.1f * eps[2];
+}
+#define GLABC_USER_PRIOR 1
+/* independent Laplace coordinates of scale 1.5: -(|t0| + |t1|) / 1.5 - 2 log 3 */
+GLABC_SIMULATOR float glabc_user_prior_log_prob(const float* theta)
+{
+    return -((fabsf(theta[0]) + fabsf(theta[1])) / 1.5f) - 2.1972246f;
+}
+#define GLABC_USER_DISCREPANCY 1
+/* a weighted L1 distance */
+GLABC_SIMULATOR float glabc_user_discrepancy(const float* y, const float* y_obs)
+{
+    return (fabsf(y[0] - y_obs[0]) + 0.5f * fabsf(y[1] - y_obs[1])) + 2.0f * fabsf(y[2] - y_obs[2]);
+}
+#define GLABC_USER_KERNEL 1
+/* Epanechnikov kernel of width 3 scale in logs, with a steep linear tail instead of -inf */
+GLABC_SIMULATOR float glabc_user_log_kernel(float dis, float scale)
+{
+    const float u = dis / (3.0f * scale);
+    return u < 0.9f ? glabc_logf(1.0f - u * u) : -1.6607312f - 40.0f * (u - 0.9f);
+}
+"""
+PRIOR_ONLY = ALL_USER[:ALL_USER.index("#define GLABC_USER_DISCREPANCY")]
 
 
 def user_model_desc(model, nd):
@@ -291,3 +340,111 @@ def test_hip_compiled_model_also_runs_the_other_paths(hip):
     assert np.array_equal(bits(a.numpy()), bits(b.numpy())) and (a[1:] != a[:-1]).any()
     c = g_.GLMALA(cm, 20, th0[:64], y0[:64], 0.2, 8, None, 0.5, ip, 4, seed=3, verbose=False)
     assert c.shape == (20, 64, 3) and torch.isfinite(c).all()
+
+
+def test_oracle_takes_user_prior_discrepancy_and_kernel(oracle):
+    """oracle_set_user_model: the checker evaluates a user Model's prior / discrepancy / kernel through the host build of the same
+    source (its row-wise twins of the Model callbacks included), and falls back to the descriptor's forms where a callback is
+    not replaced"""
+    lib, fn = host_simulator(ALL_USER, 2, 3, 3)
+    oracle.oracle_set_user_simulator(fn)
+    oracle.oracle_set_user_model(*host_hooks(lib))
+    try:
+        import glabcmcmc_amd as g_
+        cm = g_.CompiledModel(2, 3, ALL_USER, make_dist(("gauss", [0.0, 0.0], [1.5, 1.5])), [1.0, 0.5, 0.7], 0.4, noise_dim=3)
+        assert cm.user_prior and cm.user_discrepancy and cm.user_kernel
+        m = cm.descriptor()
+        rng = np.random.default_rng(2)
+        th = rng.standard_normal((50, 2)).astype(np.float32)
+        y = rng.standard_normal((50, 3)).astype(np.float32)
+        out = np.zeros(50, np.float32)
+        assert oracle.oracle_model_prior_log_prob(C.byref(m), th.ctypes.data, 50, out.ctypes.data) == 0
+        want = -((np.abs(th[:, 0]) + np.abs(th[:, 1])) / np.float32(1.5)) - np.float32(2.1972246)
+        assert np.array_equal(bits(out), bits(want.astype(np.float32)))
+        assert oracle.oracle_model_discrepancy(C.byref(m), y.ctypes.data, 50, out.ctypes.data) == 0
+        yo = np.array([1.0, 0.5, 0.7], np.float32)
+        want = (np.abs(y[:, 0] - yo[0]) + np.float32(0.5) * np.abs(y[:, 1] - yo[1])) + np.float32(2.0) * np.abs(y[:, 2] - yo[2])
+        assert np.array_equal(bits(out), bits(want.astype(np.float32)))
+        dis = out.copy()
+        assert oracle.oracle_model_log_kernel(C.byref(m), y.ctypes.data, 50, out.ctypes.data) == 0
+        for r in range(50):
+            assert bits(np.float32(lib.glabc_user_kern_host(float(dis[r]), float(m.kern_scale)))) == bits(out[r])
+        oracle.oracle_set_user_model(host_hooks(lib)[0], None, None)              # only the prior replaced: Euclidean + Gaussian again
+        assert oracle.oracle_model_discrepancy(C.byref(m), y.ctypes.data, 50, out.ctypes.data) == 0
+        assert np.allclose(out, np.sqrt(((y - yo) ** 2).sum(1)), rtol=1e-6)
+    finally:
+        oracle.oracle_set_user_model(None, None, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source,algo,N", [(ALL_USER, "glmcmc", 5), (ALL_USER, "glmcmc", 16), (ALL_USER, "globalmcmc", 1),
+                                            (PRIOR_ONLY, "glmcmc", 7)], ids=["all-glmcmc5", "all-glmcmc16", "all-global", "prior-glmcmc7"])
+def test_hip_user_prior_discrepancy_and_kernel_equal_oracle(hip, oracle, source, algo, N):
+    """The Model's OTHER callbacks as user source (include/glabc.h): a Laplace prior, a weighted L1 discrepancy and an Epanechnikov
+    kernel compiled into the fused kernel next to the simulator.  Kernel == checker (same source through hiprtc and gcc) bit for
+    bit -- histories, states, log-weights, sums --, the protocol methods on rows == the host build, and (CompiledModel's
+    self-check, run when the program is built) fused == split-phase."""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import engine
+    cm = g_.CompiledModel(2, 3, source, make_dist(("gauss", [0.0, 0.0], [1.5, 1.5])), [1.0, 0.5, 0.7], 0.4, noise_dim=3)
+    assert cm.user_prior and cm.user_discrepancy == (source is ALL_USER) and cm.user_kernel == (source is ALL_USER)
+    lib, fn = host_simulator(source, 2, 3, 3)
+    oracle.oracle_set_user_simulator(fn)
+    oracle.oracle_set_user_model(*host_hooks(lib))
+    try:
+        model = cm.descriptor()
+        local = make_dist(("gauss", [0.0, 0.0], [0.3, 0.3])).descriptor()
+        glob = make_dist(("gauss", [0.0, 0.0], [1.6, 1.6])).descriptor()
+        rng = np.random.default_rng(N)
+        n, T, seed, gf, chain0 = 1200, 60, 777 + N, 0.6, 10 ** 10
+        theta0 = rng.standard_normal((n, 2)).astype(np.float32)
+        y0 = cm.generate_samples(torch.from_numpy(theta0)).numpy().copy()
+        dev = torch.device("cuda", 0)
+        chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0)
+        hist = torch.empty(T, 2, n, device=dev)
+        mom = engine.Moments(n, 2, dev)
+        a = A.ALGO_GLMCMC if algo == "glmcmc" else A.ALGO_GLOBALMCMC
+        prog = cm.program(a, N)                                                   # compiles + self-check (fused == split-phase)
+        hooks = [C.c_int32(-1) for _ in range(3)]
+        assert hip.glabc_rtc_hooks(prog, *[C.byref(h) for h in hooks]) == 0
+        assert [h.value for h in hooks] == [1, int(source is ALL_USER), int(source is ALL_USER)]
+        engine.run_steps(None, model, local, glob, chains, T, 1, seed, gf, N, history=hist, moments=mom, steps_per_launch=25,
+                         rtc_program=prog)
+        torch.cuda.synchronize()
+        hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
+        hh = np.zeros((T, 2, n), np.float32)
+        hm = oracle_lib.HostMoments(n, 2)
+        run, k2 = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=N, history=hh, moments=hm)
+        cs = hc.struct()
+        fn_o = oracle.oracle_glmcmc_steps if algo == "glmcmc" else oracle.oracle_globalmcmc_steps
+        assert fn_o(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run)) == 0
+        assert np.array_equal(bits(hist.cpu().numpy()), bits(hh)) and hc.n_moves.sum() > n
+        assert np.array_equal(bits(chains.y.cpu().numpy()), bits(hc.y))
+        if algo == "glmcmc":
+            assert np.array_equal(bits(chains.log_w.cpu().numpy()), bits(hc.log_w))
+        assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump) and np.array_equal(mom.sum_outer.cpu().numpy(), hm.sum_outer)
+        # the protocol methods on rows == the host build of the same functions
+        th = torch.from_numpy(theta0[:64]).cuda()
+        yy = torch.from_numpy(y0[:64]).cuda()
+        pr, kk = cm.prior_log_prob(th).cpu().numpy(), cm.calculate_log_kernel(yy).cpu().numpy()
+        yo = np.array([1.0, 0.5, 0.7], np.float32)
+        for r in range(64):
+            assert bits(pr[r]) == bits(np.float32(lib.glabc_user_prior_host(theta0[r].ctypes.data)))
+        if source is ALL_USER:
+            ds = cm.discrepancy(yy).cpu().numpy()
+            for r in range(64):
+                d = np.float32(lib.glabc_user_dis_host(y0[r].ctypes.data, yo.ctypes.data))
+                assert bits(ds[r]) == bits(d)
+                assert bits(kk[r]) == bits(np.float32(lib.glabc_user_kern_host(float(d), float(model.kern_scale))))
+        # ... and the whole Model through MCMCRunner, fused and split-phase, gives one and the same chains
+        runner = g_.MCMCRunner(cm)
+        lp = make_dist(("gauss", [0.0, 0.0], [0.3, 0.3]))
+        ip = make_dist(("gauss", [0.0, 0.0], [1.6, 1.6]))
+        if algo == "glmcmc":
+            kw = dict(seed=5, output_file=None, verbose=False)
+            fused = runner.run_glmcmc(41, torch.from_numpy(theta0[:300]), torch.from_numpy(y0[:300]), 0.6, lp, ip, N, **kw)
+            split = runner.run_glmcmc(41, torch.from_numpy(theta0[:300]), torch.from_numpy(y0[:300]), 0.6, lp, ip, N, path="generic",
+                                      sentinel_redraw=False, **kw)
+            assert np.array_equal(bits(fused.numpy()), bits(split.numpy()))
+    finally:
+        oracle.oracle_set_user_model(None, None, None)
