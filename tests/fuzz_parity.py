@@ -244,9 +244,38 @@ def random_simulator(rng, d, yd, nd):
     return "GLABC_SIMULATOR void glabc_user_simulate(const float* theta, const float* eps, float* y)\n{\n%s\n}\n" % "\n".join(lines)
 
 
+def random_hooks(rng, d, yd):
+    """C source of random replacements of the Model's other callbacks (include/glabc.h, "The Model's OTHER callbacks as user
+    source"): each of prior / discrepancy / kernel is announced with probability 1/2"""
+    src = ""
+    if rng.random() < 0.5:
+        s = repr(round(float(rng.uniform(0.6, 2.5)), 3))
+        terms = " + ".join(["fabsf(theta[%d])" % j if rng.random() < 0.5 else "0.5f * (theta[%d] * theta[%d])" % (j, j) for j in range(d)])
+        src += ("#define GLABC_USER_PRIOR 1\nGLABC_SIMULATOR float glabc_user_prior_log_prob(const float* theta)\n"
+                "{\n    return -((%s) / %sf) - 1.25f;\n}\n" % (terms, s))
+    if rng.random() < 0.5:
+        kind = int(rng.integers(0, 3))
+        if kind == 0:                                                  # weighted L1
+            body = "    float s = 0.0f;\n" + "".join("    s += %sf * fabsf(y[%d] - y_obs[%d]);\n" % (repr(round(float(rng.uniform(0.3, 2.0)), 2)), j, j)
+                                                     for j in range(yd)) + "    return s;\n"
+        elif kind == 1:                                                # L-infinity
+            body = "    float s = 0.0f;\n" + "".join("    s = fmaxf(s, fabsf(y[%d] - y_obs[%d]));\n" % (j, j) for j in range(yd)) + "    return s;\n"
+        else:                                                          # Euclidean in another summation order
+            body = "    float s = 0.0f;\n" + "".join("    s = fmaf(y[%d] - y_obs[%d], y[%d] - y_obs[%d], s);\n" % (j, j, j, j)
+                                                     for j in reversed(range(yd))) + "    return sqrtf(s);\n"
+        src += "#define GLABC_USER_DISCREPANCY 1\nGLABC_SIMULATOR float glabc_user_discrepancy(const float* y, const float* y_obs)\n{\n%s}\n" % body
+    if rng.random() < 0.5:
+        body = ["    return -dis / scale;\n",
+                "    const float u = dis / (3.0f * scale);\n    return u < 0.9f ? glabc_logf(1.0f - u * u) : -1.6607312f - 40.0f * (u - 0.9f);\n",
+                "    const float u = dis / scale;\n    return -glabc_logf(1.0f + u * u);\n"][int(rng.integers(0, 3))]
+        src += "#define GLABC_USER_KERNEL 1\nGLABC_SIMULATOR float glabc_user_log_kernel(float dis, float scale)\n{\n%s}\n" % body
+    return src
+
+
 def one_case_rtc(rng, oracle, k):
     """A random user simulator compiled into the fused kernel at run time (glabc_rtc_compile) vs the checker calling the same
-    source through gcc; theta_dim / y_dim / noise_dim 1..8, N 1..16."""
+    source through gcc; theta_dim / y_dim / noise_dim 1..8, N 1..16; every other case replaces a random subset of the Model's prior / discrepancy /
+    kernel by user source too."""
     import glabcmcmc_amd as g_
     from test_rtc import host_simulator
     d, yd, nd = int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(1, 9))
@@ -255,8 +284,12 @@ def one_case_rtc(rng, oracle, k):
     algo = "glmcmc" if rng.random() < 0.8 else "globalmcmc"
     N = int(rng.integers(1, 17)) if algo == "glmcmc" else 1
     src = random_simulator(rng, d, yd, nd)
+    if rng.random() < 0.5:
+        src += random_hooks(rng, d, yd)           # the Model's prior / discrepancy / kernel as user source as well
+    from test_rtc import host_hooks
     keep_lib, fn = host_simulator(src, d, yd, nd)
     oracle.oracle_set_user_simulator(fn)
+    oracle.oracle_set_user_model(*host_hooks(keep_lib))
     eps = float(np.exp(rng.uniform(np.log(0.05), np.log(5))))
     gf = float(rng.choice([0.0, 1.0, rng.random()]))
     lspec, gspec = random_dist(rng, d, True), random_dist(rng, d, False)
@@ -294,6 +327,7 @@ def one_case_rtc(rng, oracle, k):
     if algo == "glmcmc":
         ok = ok and np.array_equal(bits(chains.log_w.cpu().numpy()), bits(hc.log_w))
     del cm
+    oracle.oracle_set_user_model(None, None, None)
     return ok, desc, int(hc.n_moves.sum())
 
 
