@@ -587,7 +587,8 @@ def bench_rtc(args):
            "compile_seconds": compile_s, "esjd_mean": float(esjd[ok].double().mean()),
            "mean_theta_sq": float(mom.second_moment().diagonal(dim1=1, dim2=2).mean()), "analytic_mean_theta_sq": 2.081014,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "glabc::sampler_kernel<GLMCMC, D=2, N=%d, VAR_GAUSS_UNIT> (hiprtc)" % N,
+                        "traffic": None, "kernel": ("glabc::team_sampler_kernel<D=2, N=%d, VAR_GAUSS_UNIT, %d wavefronts per 64 chains> (hiprtc)" % (N, 3 if n <= 65536 else 2)
+                                   if 16384 <= n <= 131072 and N >= 2 else "glabc::sampler_kernel<GLMCMC, D=2, N=%d, VAR_GAUSS_UNIT> (hiprtc)" % N),
                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
                         "note": "VALU-bound like the built-in kernel; the host picks the unit-Gaussian or the generic instantiation "
                                 "per launch as for the built-in Models (default schedule, the user's simulator inlined)"}}

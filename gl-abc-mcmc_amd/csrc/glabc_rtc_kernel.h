@@ -27,6 +27,31 @@ template __global__ void sampler_kernel<GLABC_RTC_ALGO, GLABC_RTC_D, GLABC_RTC_Y
     const StepArgs<GLABC_RTC_D, GLABC_RTC_YD>);
 #endif
 
+// ... and the team geometry of glabc_team.h (two or three wavefronts per 64 chains: what the built-in GLMCMC kernels run at 16 384 ..
+// 131 072 chains), where the host found the configuration to fit (GLABC_RTC_TEAM3 / GLABC_RTC_TEAM2)
+#if GLABC_RTC_ALGO == 0 && (defined(GLABC_RTC_TEAM3) || defined(GLABC_RTC_TEAM2))
+}  // namespace glabc
+#include "glabc_team.h"
+namespace glabc {
+#define GLABC_RTC_TEAM_INST(NW_, VAR_)                                                                                         \
+    template __global__ void team_sampler_kernel<GLABC_RTC_D, GLABC_RTC_YD, GLABC_RTC_N, VAR_, NW_, false>(                   \
+        const StepArgs<GLABC_RTC_D, GLABC_RTC_YD>, int);
+#ifdef GLABC_RTC_TEAM3
+GLABC_RTC_TEAM_INST(3, VAR_GENERIC)
+#endif
+#ifdef GLABC_RTC_TEAM2
+GLABC_RTC_TEAM_INST(2, VAR_GENERIC)
+#endif
+#if GLABC_RTC_YD == GLABC_RTC_D && !defined(GLABC_USER_PRIOR) && !defined(GLABC_USER_DISCREPANCY) && !defined(GLABC_USER_KERNEL)
+#ifdef GLABC_RTC_TEAM3
+GLABC_RTC_TEAM_INST(3, VAR_GAUSS_UNIT)
+#endif
+#ifdef GLABC_RTC_TEAM2
+GLABC_RTC_TEAM_INST(2, VAR_GAUSS_UNIT)
+#endif
+#endif
+#endif
+
 // generate_samples(theta, 1) on rows with the noise supplied (the Model protocol's callback, for y0 and the split-phase path):
 // theta[n][D], eps[n][ND] -> y[n][YD]
 extern "C" __global__ void __launch_bounds__(256) glabc_rtc_simulate_rows(const float* __restrict__ theta, const float* __restrict__ eps,

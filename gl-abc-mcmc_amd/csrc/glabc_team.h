@@ -112,7 +112,7 @@ GLABC_DEV void team_candidate(const StepArgs<D, YD>& a, const Rng& rng, uint32_t
         lq = lc ? dist_log_prob<D, GU>(a.global, th) : dist_forward_log_p<D, GU>(a.global, e);
     }
     model_simulate<D, YD>(a, th, s, yy);
-    pr = dist_log_prob<D, GU>(a.prior, th);
+    pr = model_prior<D, YD, GU, false>(a, th);
     kk = model_log_kernel<D, YD, GU, FAST>(a, yy);
     lw = (pr + kk) - lq;                                                      // GLMCMC.py:74
     const float v = FAST ? fast_expf(lw) : glabc_expf(lw);                    // GLMCMC.py:78
