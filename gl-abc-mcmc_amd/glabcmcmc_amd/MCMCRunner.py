@@ -1,5 +1,13 @@
 """MCMCRunner -- the facade of the reference (MCMCRunner.py:6-121), same constructor and
-``run_*`` signatures; extra keyword arguments are forwarded to the sampler functions."""
+``run_*`` signatures; extra keyword arguments are forwarded to the sampler functions.
+
+A Model that is a plain Python object (no ``descriptor()``) runs through the split-phase path (generic.py).  With
+``graph='auto'`` (the default) one iteration of that path -- the two HIP kernels AND the Model's own callbacks -- is captured
+once as a hipGraph and replayed.  A capture freezes everything the callbacks do on the HOST: Python / NumPy scalars read per
+call, counters, data-dependent Python branches, copies from pageable host memory.  Callbacks that are pure functions of
+their tensor arguments (and of torch's CUDA generator, which graphs handle) are safe -- that is every Model written like
+examples/Mixture.py; anything else must pass ``graph=False`` (same chains, launched eagerly).  A capture that cannot be
+made at all (a callback that synchronises) falls back to eager launches by itself."""
 import os
 
 
