@@ -515,3 +515,22 @@ def test_hip_rtc_team_geometry_is_only_geometry(hip, oracle, which, N):
             assert np.array_equal(bits(res[0]), bits(res[1]))
     finally:
         oracle.oracle_set_user_model(None, None, None)
+
+
+@pytest.mark.gpu
+def test_hip_compiled_user_model_example_reaches_the_posterior(hip):
+    """examples/CompiledUserModel.py: the reference's example Model with ALL four callbacks written as user C source, through
+    MCMCRunner on the fused path -- the pooled second moment of the chains is the analytic stationary value, and
+    the compiled callbacks on rows equal the built-in Mixture_set's row-wise kernels to float32 rounding."""
+    from glabcmcmc_amd.examples import CompiledUserModel as ex
+    from glabcmcmc_amd.examples.Mixture import Mixture_set
+    got = ex.main(n_chains=16384, num_ite=400, burn=200)
+    want = ex.analytic_second_moment()
+    assert all(abs(g - want) < 6e-3 * want for g in got), (got, want)
+    cm, ref = ex.build(), Mixture_set(0.05)
+    gen = torch.Generator().manual_seed(0)
+    th = torch.randn(200, 2, generator=gen).cuda()
+    y = (th.abs() + 0.2 * torch.randn(200, 2, generator=gen).cuda())
+    assert torch.allclose(cm.prior_log_prob(th), ref.prior_log_prob(th).view(-1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(cm.discrepancy(y), ref.discrepancy(y).view(-1), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(cm.calculate_log_kernel(y), ref.calculate_log_kernel(y).view(-1), rtol=1e-4, atol=1e-4)
