@@ -958,7 +958,7 @@ def main():
         # read correction applied) for exactly this configuration: profiles/r01_f_pmc_summary.json
         # the launch geometry glabc_glmcmc_steps picks (csrc/glabc_hip.hip run_sampler): teams of wavefronts for launches of
         # 16 384 .. 131 072 chains when the caller leaves the geometry to the library
-        team_geometry = args.workload in ("glmcmc", "gk") and 2 <= args.batch <= 16 and args.lanes == 0 and \
+        team_geometry = args.workload in ("glmcmc", "gk", "gamma") and 2 <= args.batch <= 16 and args.lanes == 0 and \
             not (args.debug_flags & 2) and ((args.debug_flags & 4) or 16384 <= n <= 131072)
         traffic, valu = None, None
         p = counted(args.workload + ("_fast" if args.fast_math else ""), n, K, args.batch if args.workload in ("glmcmc", "gk", "gamma") else None)
@@ -1000,7 +1000,8 @@ def main():
                                     else "glabc::glmala_kernel<D=2, N=5>",
                                     "gk": "glabc::team_sampler_kernel<D=4, YD=8, N=%d>" % args.batch if team_geometry
                                     else "glabc::sampler_kernel<GLMCMC, D=4, YD=8, N=%d>" % args.batch,
-                                    "gamma": "glabc::sampler_kernel<GLMCMC, D=2, N=%d, VAR_GAMMA>" % args.batch}[args.workload], "kernel_ms": kernel_ms,
+                                    "gamma": ("glabc::team_sampler_kernel<D=2, N=%d, VAR_GAMMA, %d wavefronts per 64 chains>" % (args.batch, 3 if n <= 65536 and args.batch >= 3 else 2))
+                                    if team_geometry else "glabc::sampler_kernel<GLMCMC, D=2, N=%d, VAR_GAMMA>" % args.batch}[args.workload], "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_chain_step": algo_bytes / (n * K),
                          "valu": valu,

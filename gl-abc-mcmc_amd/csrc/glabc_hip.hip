@@ -691,9 +691,9 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
     }
     // Team geometry (glabc_team.h): two wavefronts per 64 chains, for launches that would otherwise leave the SIMDs with at most
     // two wavefronts of sampler_kernel each.  Chosen when the caller leaves the geometry to the library.
-    const bool gamma = m->prior.kind == GLABC_DIST_GAMMA || global->kind == GLABC_DIST_GAMMA;      // VAR_GAMMA: one lane per chain
+    const bool gamma = m->prior.kind == GLABC_DIST_GAMMA || global->kind == GLABC_DIST_GAMMA;      // VAR_GAMMA: one lane per chain, or a team of two / three wavefronts
     const bool fast = r->math_mode == GLABC_MATH_FAST;      // runs the team kernels whatever the launch size
-    if (algo == ALGO_GLMCMC && !r->tape && !gamma && (fast || !(r->debug_flags & GLABC_DEBUG_NO_TEAM)) &&
+    if (algo == ALGO_GLMCMC && !r->tape && !(gamma && (fast || m->sim_kind != GLABC_SIM_ABS_GAUSS)) && (fast || !(r->debug_flags & GLABC_DEBUG_NO_TEAM)) &&
         (fast || (r->debug_flags & GLABC_DEBUG_TEAM) || (r->lanes_per_chain == 0 && c->n_chains >= 64 * 256 && c->n_chains <= 2 * 1024 * 64))) {
         int prio = 1;                                       // the main wavefront carries the serial part of an iteration
         if (const char* e = std::getenv("GLABC_TEAM_PRIO")) prio = std::max(0, std::min(3, std::atoi(e)));

@@ -61,6 +61,7 @@ GLABC_DEV void team_candidate(const StepArgs<D, YD>& a, const Rng& rng, uint32_t
                               int n_prop = 0, bool dump = false)
 {
     constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
+    constexpr bool GM = (VAR == VAR_GAMMA);               // GLABC_DIST_GAMMA as the importance proposal / the prior (glabc_device.h)
     constexpr int DP = D + (D & 1);
     constexpr int ND = NoiseDim<YD>::value;
     constexpr int M = DP + ND;
@@ -102,6 +103,18 @@ GLABC_DEV void team_candidate(const StepArgs<D, YD>& a, const Rng& rng, uint32_t
         const float t = p0 + p2 * e[q];                                       // distribution.py:170 / :77
         th[q] = lc ? (t + c.theta[q]) : t;                                    // GLMCMC.py:91
     }
+    // a Gamma importance proposal (wave-uniform): the candidate and forward()'s log q from the chain's Gamma slots, exactly as
+    // chain_step draws them; a lane on the local branch keeps candidate 0 as built above
+    float lq_gamma = 0.0f;
+    const bool g_gam = GM && a.global.kind == GLABC_DIST_GAMMA;
+    if constexpr (GM) {
+        if (g_gam) {
+            float tg[D];
+            dist_gamma_forward<D>(a.global, rng.c0, rng.c1, rng.k0, rng.k1, step, j, tg, lq_gamma);
+#pragma unroll
+            for (int q = 0; q < D; ++q) th[q] = lc ? th[q] : tg[q];
+        }
+    }
     float lq;
     if constexpr (GU) {
         float v[D];                                                           // both are c0 - sum 0.5 v^2 in the unit variant
@@ -109,10 +122,10 @@ GLABC_DEV void team_candidate(const StepArgs<D, YD>& a, const Rng& rng, uint32_t
         for (int q = 0; q < D; ++q) v[q] = lc ? (th[q] - a.global.p0[q]) : e[q];
         lq = dist_forward_log_p<D, GU>(a.global, v);
     } else {
-        lq = lc ? dist_log_prob<D, GU>(a.global, th) : dist_forward_log_p<D, GU>(a.global, e);
+        lq = lc ? dist_log_prob<D, GU, GM>(a.global, th) : (g_gam ? lq_gamma : dist_forward_log_p<D, GU>(a.global, e));
     }
     model_simulate<D, YD>(a, th, s, yy);
-    pr = model_prior<D, YD, GU, false>(a, th);
+    pr = model_prior<D, YD, GU, GM>(a, th);
     kk = model_log_kernel<D, YD, GU, FAST>(a, yy);
     lw = (pr + kk) - lq;                                                      // GLMCMC.py:74
     const float v = FAST ? fast_expf(lw) : glabc_expf(lw);                    // GLMCMC.py:78
@@ -150,6 +163,7 @@ template <int D, int YD, int N, int VAR, int NW, bool FAST = false>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) team_sampler_kernel(const StepArgs<D, YD> a, int prio)
 {
     constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
+    constexpr bool GM = (VAR == VAR_GAMMA);
     static_assert(NW >= 2 && NW <= 4 && team_split_ok(N, NW), "team of two to four wavefronts, at least one candidate each");
     constexpr int NA = team_main_candidates(N, NW), NH = N - NA;
     __shared__ TeamCand<D, YD, NH> buf[2];
@@ -188,7 +202,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
     c.flags = a.flags[i];
     c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
     c.gf = a.gf_chain ? a.gf_chain[i] : a.gf;
-    refresh_cache<D, YD>(a, c);
+    refresh_cache<D, YD, GM>(a, c);
     if constexpr (FAST) c.kern = model_log_kernel<D, YD, false, true>(a, c.y);             // the cached K(y_old) in the arithmetic of the candidates
     c.lw_cur = (c.flags & GLABC_FLAG_LOCAL) ? (c.prior + c.kern) - c.q : c.log_w;          // GLMCMC.py:60-64
     {
@@ -320,7 +334,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
                 for (int q = 0; q < YD; ++q) c.y[q] = ny[q];
                 c.prior = npr;
                 c.kern = nkk;
-                c.q = dist_log_prob<D, GU>(a.global, c.theta);
+                c.q = dist_log_prob<D, GU, GM>(a.global, c.theta);
                 c.lw_cur = nlw;
                 c.w_cur = nw;
                 if (is_global)

@@ -17,7 +17,13 @@ static int launch_team(const StepArgs<D, YD>& a, int prio, hipStream_t s)
 {
     if constexpr (team_config_ok(D, YD, N, NW) && (!FAST || YD == D)) {
         const unsigned grid = (unsigned)((a.n_chains + 63) / 64);
-        if (gauss_unit_config<D, YD>(a))
+        if (a.prior.kind == GLABC_DIST_GAMMA || a.global.kind == GLABC_DIST_GAMMA) {
+            // VAR_GAMMA (float64 draws and densities): teams of two and three wavefronts, the |theta| + noise simulator, exact arithmetic
+            if constexpr (NW <= 3 && YD == D && !FAST)
+                hipLaunchKernelGGL((team_sampler_kernel<D, YD, N, VAR_GAMMA, NW, false>), dim3(grid), dim3(64 * NW), 0, s, a, prio);
+            else
+                return GLABC_ERR_ARG;
+        } else if (gauss_unit_config<D, YD>(a))
             hipLaunchKernelGGL((team_sampler_kernel<D, YD, N, (YD == D ? VAR_GAUSS_UNIT : VAR_GENERIC), NW, FAST>), dim3(grid), dim3(64 * NW), 0, s, a, prio);
         else
             hipLaunchKernelGGL((team_sampler_kernel<D, YD, N, VAR_GENERIC, NW, FAST>), dim3(grid), dim3(64 * NW), 0, s, a, prio);

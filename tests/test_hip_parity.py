@@ -6,6 +6,7 @@
 GPU only:  python -m pytest tests -m gpu
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1108,6 +1109,19 @@ def test_gamma_inside_the_fused_kernels(hip, oracle, case):
     assert hc.n_moves.sum() > n // 4
     if pspec:
         assert (hist[T // 2:] >= 0).all()                   # a Gamma prior: no state outside its support survives
+    if algo == "glmcmc" and 2 <= N <= 16:
+        # ... and in the team geometry (csrc/glabc_team.h: two / three wavefronts per 64 chains, what a launch of 16 384 .. 131 072
+        # chains gets): the helpers draw their Gamma candidates from the same slots -- the same bits again
+        for waves in ("2", "3"):
+            os.environ["GLABC_TEAM_WAVES"] = waves
+            try:
+                h2, c2, m2 = hip_run(algo, model, local, glob, theta0, y0, T, seed, gf, N, chain0=chain0, moments=True,
+                                     steps_per_launch=33, debug_flags=A.DEBUG_TEAM)
+            finally:
+                del os.environ["GLABC_TEAM_WAVES"]
+            assert (bits(h2) == bits(hh)).all(), waves
+            assert_same_state(c2, hc, True)
+            assert np.array_equal(m2.sum_jump.cpu().numpy(), hm.sum_jump)
 
 
 def test_gamma_split_phase_equals_fused(hip):

@@ -161,6 +161,34 @@ def test_every_wide_and_team_instantiation_equals_the_checker(product, oracle, d
         monkeypatch.delenv("GLABC_TEAM_WAVES", raising=False)
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_every_gamma_instantiation_equals_the_checker(product, oracle, d, monkeypatch):
+    """VAR_GAMMA (a Gamma importance proposal and a Gamma prior, distribution.py:90-137): sampler_kernel<GLMCMC, D, D, N, 1,
+    VAR_GAMMA> for N 1..16, GlobalMCMC, and team_sampler_kernel<D, D, N, VAR_GAMMA, NW> for NW 2 / 3 x N 2..16 -- built without
+    the SLP vectorizer, walked all the same"""
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import distribution
+    model = _model(d)
+    model.prior = distribution.Gamma(torch.full((d,), 2.0), torch.full((d,), 1.0)).descriptor()
+    local = make_dist(("gauss", [0.0] * d, [0.3] * d)).descriptor()
+    glob = distribution.Gamma(torch.full((d,), 4.0), torch.full((d,), 3.0)).descriptor()
+    theta0, y0 = _inputs(d, d, 300 + d)
+    theta0 = np.abs(theta0) + np.float32(0.2)                   # inside the Gamma prior's support
+    for N in range(1, 17):
+        want = _run_oracle(oracle, "glmcmc", model, local, glob, theta0, y0, N, 6000 + N)
+        got = _run_lib(product, "glmcmc", model, local, glob, theta0, y0, N, 0, A.DEBUG_NO_TEAM, 6000 + N)
+        _same(got, want, True, dict(d=d, N=N, kernel="gamma one lane"))
+        if N >= 2:
+            for nw in (2, 3):
+                monkeypatch.setenv("GLABC_TEAM_WAVES", str(nw))
+                got = _run_lib(product, "glmcmc", model, local, glob, theta0, y0, N, 0, A.DEBUG_TEAM, 6000 + N)
+                _same(got, want, True, dict(d=d, N=N, team=nw, kernel="gamma"))
+            monkeypatch.delenv("GLABC_TEAM_WAVES", raising=False)
+    want = _run_oracle(oracle, "globalmcmc", model, local, glob, theta0, y0, 1, 98)
+    got = _run_lib(product, "globalmcmc", model, local, glob, theta0, y0, 1, 0, 0, 98)
+    _same(got, want, False, dict(d=d, algo="globalmcmc", kernel="gamma"))
+
+
 def _gk(eps=0.6):
     from glabcmcmc_amd import distribution
     from glabcmcmc_amd.examples.GK import GK_set
