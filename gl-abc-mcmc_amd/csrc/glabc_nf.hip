@@ -364,6 +364,74 @@ __device__ __forceinline__ void coupling_params2_ahead(const float* __restrict__
     log_s_b = ((half ? qb1 : pb1) + (half ? pb1 : qb1)) + b31;
 }
 
+// The same for ONE row tile per wavefront (tile mode: inputs of at most eight tiles per workgroup): groups of four k steps = four
+// MFMAs behind their four B operands, operands fetched one group ahead, b2 as the C operand of a tile's first MFMA.
+template <int T>
+__device__ __forceinline__ void nf_tile_pass_ahead1(const float* __restrict__ lds, float z0, int half, int col, f32x16& x, const f32x16& y,
+                                                    NfOps& cur, f32x16& c, float& p0, float& p1)
+{
+    constexpr int TN = (T + 1) & 3;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        NfOps nxt;
+        if (g < 15) nf_fetch_ops(lds, half, col, T, g + 1, nxt);
+        else nf_fetch_ops(lds, half, col, TN, 0, nxt);
+        f32x16 cn = c;
+        if (g >= 1) {
+            const int r = g == 1 ? 0 : g;
+            cn[r] = lds[L_V4 + 4 * (32 * TN + (r & 3) + 8 * (r >> 2) + 4 * half)];
+            if (g == 1) cn[1] = lds[L_V4 + 4 * (32 * TN + 1 + 4 * half)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = __builtin_fmaxf(__builtin_fmaf(cur.w[q], z0, cur.bi[q]), 0.0f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (g == 0 && q == 0) x = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.wv[q], h[q], c, 0, 0, 0);
+            else x = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.wv[q], h[q], x, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if constexpr (T > 0) {
+            const float q2 = __builtin_fmaxf(y[g], 0.0f);
+            p0 = __builtin_fmaf(cur.v.x, q2, p0);
+            p1 = __builtin_fmaf(cur.v.y, q2, p1);
+        }
+        cur = nxt;
+        c = cn;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void coupling_params_ahead(const float* __restrict__ lds, float z0, int lane, float& shift, float& log_s)
+{
+    const int half = lane >> 5, col = lane & 31;
+    NfOps ops;
+    f32x16 c;
+    nf_fetch_ops(lds, half, col, 0, 0, ops);
+    nf_fetch_bias(lds, half, 0, c);
+    f32x16 a0, a1, a2, a3;
+    float p0 = 0.0f, p1 = 0.0f;
+    nf_tile_pass_ahead1<0>(lds, z0, half, col, a0, a0, ops, c, p0, p1);
+    nf_tile_pass_ahead1<1>(lds, z0, half, col, a1, a0, ops, c, p0, p1);
+    nf_tile_pass_ahead1<2>(lds, z0, half, col, a2, a1, ops, c, p0, p1);
+    nf_tile_pass_ahead1<3>(lds, z0, half, col, a3, a2, ops, c, p0, p1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = 96 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float2 v = *reinterpret_cast<const float2*>(lds + L_V4 + 4 * i + 1);
+        const float h2 = __builtin_fmaxf(a3[r], 0.0f);
+        p0 = __builtin_fmaf(v.x, h2, p0);
+        p1 = __builtin_fmaf(v.y, h2, p1);
+    }
+    const float q0 = __shfl_xor(p0, 32, 64), q1 = __shfl_xor(p1, 32, 64);
+    const float lo0 = half ? q0 : p0, hi0 = half ? p0 : q0;
+    const float lo1 = half ? q1 : p1, hi1 = half ? p1 : q1;
+    shift = (lo0 + hi0) + lds[L_B3 + 0];
+    log_s = (lo1 + hi1) + lds[L_B3 + 1];
+}
+
 // One row tile per wavefront: the form for small inputs (at most one tile per CU), where the launch is a latency chain
 // and half the MFMAs per coupling beat operand reuse.  Same arithmetic per row as coupling_params2.
 __device__ __forceinline__ void coupling_params(const float* __restrict__ lds, float z0, int lane, float& shift, float& log_s)
@@ -574,7 +642,11 @@ __global__ void __launch_bounds__(64 * NF_WAVES) nf_kernel(const NfArgs a)
         if constexpr (TILE_MODE) {
             if (tile_active) {
                 float sh, ls;
+#if GLABC_NF_FORM == 2
+                coupling_params_ahead(lds, INVERSE ? z1 : z0, lane, sh, ls);
+#else
                 coupling_params(lds, INVERSE ? z1 : z0, lane, sh, ls);
+#endif
                 if (INVERSE && a.trace && lane < 32) {
                     const int64_t row = wg_row0 + (int64_t)wave * 32 + col;
                     if (row < n_rows) a.trace[(int64_t)c * a.n_rows + row] = z1;
@@ -698,9 +770,12 @@ static int nf_launch(const NfArgs& a, hipStream_t s)
         const int w = std::atoi(force);
         if (w >= 1 && w <= NF_WAVES) return nf_launch_mode<INV, true>(a, 32 * w, 0, s);
     }
-    // up to one tile per CU (8192 rows) the launch is a latency chain of couplings: one tile per workgroup halves it
-    // against one pair per workgroup.  (With more tiles than CUs, pairs win again: 65 536 rows measured 77 vs 65 TFLOP/s.)
-    if (tiles <= (int64_t)NF_CUS) return nf_launch_mode<INV, true>(a, 32, 0, s);
+    // Up to four tiles per CU (32 768 rows) the launch is a latency chain of couplings and what counts is the longest queue of
+    // MFMAs on any SIMD: one tile per wavefront, one wavefront per SIMD (256 MFMAs per coupling) against one or two 64-row pairs
+    // on one or two of the four SIMDs (512 each) -- 0.105 against 0.16 ms at 16 384 and 32 768 rows.  From three pairs per CU on
+    // the pair form wins again (its A operands feed two MFMAs): 49 152 rows 0.166 against 0.185, 65 536 rows 0.168 against 0.186
+    // (profiles/r03c_nf_tile_ab.txt).
+    if (tiles <= 4 * (int64_t)NF_CUS) return nf_launch_mode<INV, true>(a, 32 * (int)((tiles + NF_CUS - 1) / NF_CUS), 0, s);
     const int64_t pairs = (a.n_rows + 63) / 64;
     int64_t pairs_per_wg = (pairs + NF_CUS - 1) / NF_CUS;
     const int64_t cap = (int64_t)NF_WAVES * NF_MAX_PAIRS;

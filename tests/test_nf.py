@@ -71,7 +71,8 @@ def test_zero_initialised_flow_is_the_base(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_couplings,n", [(1, 100), (3, 513), (8, 4096), (32, 1000), (2, 70001), (1, 140000)])
+@pytest.mark.parametrize("n_couplings,n", [(1, 100), (3, 513), (8, 4096), (32, 1000), (2, 8193), (3, 20000), (2, 32768), (2, 32800),
+                                           (2, 70001), (1, 140000)])
 def test_mfma_kernels_equal_oracle(hip, oracle, n_couplings, n):
     flow = make_flow(n_couplings, 20 + n_couplings)
     f, blob = host_descriptor(flow)
