@@ -995,7 +995,9 @@ def main():
                                                % (args.batch, 3 if n <= 65536 and args.batch >= 3 else 2)
                                                if team_geometry else "glabc::sampler_kernel<GLMCMC, D=2, N=%d>" % args.batch)
                                     if args.batch <= 16 else "glabc::wide_kernel<D=2, L> N=%d" % args.batch,
-                                    "globalmcmc": "glabc::sampler_kernel<GLOBAL, D=2, N=1>",
+                                    "globalmcmc": "glabc::global_team_kernel<D=2> (2 wavefronts per 64 chains)" if args.lanes == 0 and
+                                    not (args.debug_flags & 2) and ((args.debug_flags & 4) or 16384 <= n <= 131072)
+                                    else "glabc::sampler_kernel<GLOBAL, D=2, N=1>",
                                     "glmala": "glabc::glmala_team_kernel<N=5, 2 wavefronts per 64 chains>" if n < 131072 and args.lanes in (0, 2)
                                     else "glabc::glmala_kernel<D=2, N=5>",
                                     "gk": "glabc::team_sampler_kernel<D=4, YD=8, N=%d>" % args.batch if team_geometry

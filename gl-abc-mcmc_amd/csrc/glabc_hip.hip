@@ -719,6 +719,26 @@ static int run_sampler(int algo, const glabc_model* m, const glabc_dist* local, 
             return rc;
         }
     }
+    // GlobalMCMC: a team of two wavefronts per 64 chains (global_team_kernel, glabc_team.h: the helper draws an iteration's random
+    // numbers one iteration ahead), for the same launch sizes and under the same debug bits
+    if (algo == ALGO_GLOBAL && !r->tape && !gamma && !(r->debug_flags & GLABC_DEBUG_NO_TEAM) &&
+        ((r->debug_flags & GLABC_DEBUG_TEAM) || (r->lanes_per_chain == 0 && c->n_chains >= 64 * 256 && c->n_chains <= 2 * 1024 * 64))) {
+        rc = GLABC_ERR_ARG;
+        if (m->sim_kind == GLABC_SIM_GK) {
+            rc = launch_global_team_dim<4, 8>(pack_args<4, 8>(m, local, global, c, r), 1, s);
+        } else {
+            switch (m->theta_dim) {
+#define GLABC_TEAM_CASE(d) case d: rc = launch_global_team_dim<d, d>(pack_args<d>(m, local, global, c, r), 1, s); break;
+                GLABC_TEAM_CASE(1) GLABC_TEAM_CASE(2) GLABC_TEAM_CASE(3) GLABC_TEAM_CASE(4)
+#undef GLABC_TEAM_CASE
+            default: break;
+            }
+        }
+        if (rc != GLABC_ERR_ARG) {
+            if (rc == GLABC_ERR_LAUNCH) g_last_hip_error = (int)hipPeekAtLastError();
+            return rc;
+        }
+    }
     const int lanes = (algo == ALGO_GLMCMC && !r->tape && !gamma) ? pick_lanes(r->lanes_per_chain, r->batch_size, c->n_chains) : 1;
     // Two builds of the same kernels: up to two waves per SIMD (131 072 lanes on this part) a launch is latency-bound
     // and runs the max-ilp schedule (217 VGPRs, 6 % faster at 65 536 chains); larger launches need the occupancy

@@ -385,6 +385,195 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW
     }
 }
 
+// ---- GlobalMCMC (GlobalMCMC.py:37-68): a TEAM of two wavefronts per 64 chains ---------------------------------------------
+//
+// One candidate per iteration leaves nothing to split between wavefronts as above -- but 54 % of the iteration's vector
+// instructions are its RANDOM NUMBERS (Philox blocks, Box-Muller, the logarithm of the accept uniform: 173 of 319, DESIGN.md
+// 4.1), and those are a pure function of (seed, chain id, iteration) and of the chain's constant global_frequency.  The helper
+// wavefront draws them ONE ITERATION AHEAD into LDS (branch, log u, the proposal's D draws -- normals or uniforms, whichever the
+// branch's distribution takes -- and the simulator's normals); the main wavefront keeps the state and does the rest: proposal,
+// simulator, prior, kernel, log q, the MH test of :44-47 / :60-61, update, Theta_Re row, sums.  65 536 chains are then two
+// wavefronts per SIMD of about half the instructions each instead of one (which issues at best every other slot).  Geometry
+// only: the draws are chain_step's words in chain_step's arithmetic, and so is everything the main wavefront computes from them.
+constexpr int GLOBAL_TEAM_CHUNK = 8;
+template <int D, int YD>
+struct GlobalDraws {                        // one iteration, [field][lane]: conflict-free
+    float log_u[64];                        // log of the accept uniform (-inf for u = 0)
+    uint32_t is_global[64];
+    float e[D][64];                         // the proposal's draws
+    uint32_t sw[2 * ((NoiseDim<YD>::value + 1) / 2)][64];   // the Philox words of the simulator's normals (the main wavefront runs their
+                                            // Box-Muller pairs: the two wavefronts then carry about the same number of instructions)
+};
+
+template <int D, int YD, int VAR>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) global_team_kernel(const StepArgs<D, YD> a, int prio)
+{
+    constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
+    constexpr int DP = D + (D & 1);
+    constexpr int ND = NoiseDim<YD>::value;
+    constexpr int M = DP + ND;
+    constexpr int SPP = (M + 3) / 4;
+    constexpr int CH = GLOBAL_TEAM_CHUNK;                  // iterations per barrier: the wavefronts meet once per chunk, not per iteration
+    __shared__ GlobalDraws<D, YD> buf[2][CH];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    const int64_t tid = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = tid < a.n_chains;
+    const int64_t i = valid ? tid : a.n_chains - 1;        // tail lanes shadow the last chain (no stores)
+    const uint64_t gid = (uint64_t)(a.chain0 + i);
+    Rng rng;
+    rng.c0 = (uint32_t)gid;
+    rng.c1 = (uint32_t)(gid >> 32);
+    rng.k0 = a.seed_lo;
+    rng.k1 = a.seed_hi;
+    const float gf = a.gf_chain ? a.gf_chain[i] : a.gf;
+
+    if (wave != 0) {                                       // ---- helper: the draws of iteration t, one iteration ahead ----
+        const bool g_uni = !GU && a.global.kind == GLABC_DIST_UNIFORM;
+        const bool l_uni = !GU && a.local.kind == GLABC_DIST_UNIFORM;
+#pragma unroll 1
+        for (int t0 = 0; t0 < a.n_steps; t0 += CH) {
+#pragma unroll 1
+          for (int t = t0; t < t0 + CH && t < a.n_steps; ++t) {
+            const uint32_t step = a.step0 + (uint32_t)t;
+            GlobalDraws<D, YD>& o = buf[(t0 / CH) & 1][t - t0];
+            const glabc_u32x4 h = glabc_philox4x32_10(rng.c0, rng.c1, step, 0u, rng.k0, rng.k1);       // the step head, chain_step
+            const float ub = glabc_uniform_f32(h.v[0]), ua = glabc_uniform_f32(h.v[1]);
+            const bool is_global = ub < gf;                                                             // GlobalMCMC.py:39
+            o.log_u[lane] = (ua == 0.0f) ? -__builtin_inff() : glabc_logf_normal(ua);
+            o.is_global[lane] = is_global ? 1u : 0u;
+            uint32_t w[4 * SPP + 2];                       // (+2: an odd noise count reads one pad word)
+#pragma unroll
+            for (int b = 0; b < SPP; ++b) {
+                const glabc_u32x4 v = glabc_philox4x32_10(rng.c0, rng.c1, step, (uint32_t)(1 + b), rng.k0, rng.k1);   // candidate 0
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[4 * b + q] = v.v[q];
+            }
+            const bool uni = is_global ? g_uni : l_uni;
+            float nrm[DP];                                 // the proposal's pairs (words 0 .. DP-1)
+#pragma unroll
+            for (int k = 0; 2 * k < DP; ++k) glabc_normal_pair(w[2 * k], w[2 * k + 1], &nrm[2 * k], &nrm[2 * k + 1]);
+#pragma unroll
+            for (int k = 0; k < D; ++k) o.e[k][lane] = (!GU && uni) ? glabc_uniform_f32(w[k]) : nrm[k];
+#pragma unroll
+            for (int k = 0; k < 2 * ((ND + 1) / 2); ++k) o.sw[k][lane] = w[DP + k];
+          }
+            __syncthreads();                               // the chunk's draws are in LDS
+        }
+        return;
+    }
+
+    // ---- main: state, proposal, simulator, densities, decision ----
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    Chain<D, YD> c;
+#pragma unroll
+    for (int j = 0; j < D; ++j) c.theta[j] = a.theta[j * a.stride + i];
+#pragma unroll
+    for (int j = 0; j < YD; ++j) c.y[j] = a.y[j * a.stride + i];
+    c.log_w = 0.0f;
+    c.flags = 0u;
+    c.n_moves = a.n_moves ? a.n_moves[i] : 0u;
+    c.gf = gf;
+    refresh_cache<D, YD>(a, c);
+    constexpr int TRI = D * (D + 1) / 2;
+    const bool mom = a.sum_theta != nullptr;
+    double s1[D], s2[TRI], sj[TRI];
+    if (mom) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) s1[j] = a.sum_theta[j * a.stride + i];
+#pragma unroll
+        for (int k = 0; k < TRI; ++k) {
+            s2[k] = a.sum_outer[k * a.stride + i];
+            sj[k] = a.sum_jump[k * a.stride + i];
+        }
+    }
+    float* hist = a.history ? a.history + i : nullptr;
+
+#pragma unroll 1
+    for (int t0 = 0; t0 < a.n_steps; t0 += CH) {
+      __syncthreads();                                     // the helper has left this chunk's draws (it is already on the next)
+#pragma unroll 1
+      for (int t = t0; t < t0 + CH && t < a.n_steps; ++t) {
+        float prev[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) prev[j] = c.theta[j];
+        const GlobalDraws<D, YD>& in = buf[(t0 / CH) & 1][t - t0];
+        const float log_u = in.log_u[lane];
+        const bool is_global = in.is_global[lane] != 0u;
+        float e[D], sn[ND];
+#pragma unroll
+        for (int k = 0; k < D; ++k) e[k] = in.e[k][lane];
+        {
+            float nn[2 * ((ND + 1) / 2)];                  // the simulator's pairs (words DP ..): chain_step's normals nrm[DP + k]
+#pragma unroll
+            for (int k = 0; 2 * k < ND; ++k) glabc_normal_pair(in.sw[2 * k][lane], in.sw[2 * k + 1][lane], &nn[2 * k], &nn[2 * k + 1]);
+#pragma unroll
+            for (int k = 0; k < ND; ++k) sn[k] = nn[k];
+        }
+        const bool loc = !is_global;
+        float th[D], yy[YD];
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+            const float p0 = loc ? a.local.p0[q] : a.global.p0[q];
+            const float p2 = loc ? a.local.p2[q] : a.global.p2[q];
+            const float tt = p0 + p2 * e[q];                                  // distribution.py:170 / :77
+            th[q] = loc ? (tt + c.theta[q]) : tt;                             // GlobalMCMC.py:40 / :56
+        }
+        const float lq = dist_forward_log_p<D, GU>(a.global, e);              // unused by the local move
+        model_simulate<D, YD>(a, th, sn, yy);
+        const float pr = model_prior<D, YD, GU, false>(a, th);
+        const float kk = model_log_kernel<D, YD, GU>(a, yy);
+        const float pk = pr + kk;
+        const float log_acc = loc ? ((pk - c.prior) - c.kern)                 // GlobalMCMC.py:60-61
+                                  : ((((pk + c.q) - lq) - c.prior) - c.kern); // GlobalMCMC.py:44-46
+        const bool moved = log_u < log_acc;                                   // GlobalMCMC.py:47 / :62
+        if (moved) {
+#pragma unroll
+            for (int q = 0; q < D; ++q) c.theta[q] = th[q];
+#pragma unroll
+            for (int q = 0; q < YD; ++q) c.y[q] = yy[q];
+            c.prior = pr;
+            c.kern = kk;
+            c.q = dist_log_prob<D, GU>(a.global, c.theta);
+        }
+        c.n_moves += moved ? 1u : 0u;
+        if (hist && valid) {                                                  // Theta_Re[i,:] = Theta_old, GlobalMCMC.py:49,66
+#pragma unroll
+            for (int j = 0; j < D; ++j) hist[((int64_t)t * D + j) * a.hist_stride] = c.theta[j];
+        }
+        if (mom) {
+            int k = 0;
+#pragma unroll
+            for (int p = 0; p < D; ++p) {
+                s1[p] += (double)c.theta[p];
+#pragma unroll
+                for (int q = p; q < D; ++q, ++k) {
+                    s2[k] += (double)c.theta[p] * (double)c.theta[q];
+                    double dp = (double)c.theta[p] - (double)prev[p];
+                    double dq = (double)c.theta[q] - (double)prev[q];
+                    sj[k] += dp * dq;
+                }
+            }
+        }
+      }
+    }
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) a.theta[j * a.stride + i] = c.theta[j];
+#pragma unroll
+        for (int j = 0; j < YD; ++j) a.y[j * a.stride + i] = c.y[j];
+        if (a.n_moves) a.n_moves[i] = c.n_moves;
+        if (mom) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) a.sum_theta[j * a.stride + i] = s1[j];
+#pragma unroll
+            for (int k = 0; k < TRI; ++k) {
+                a.sum_outer[k * a.stride + i] = s2[k];
+                a.sum_jump[k * a.stride + i] = sj[k];
+            }
+        }
+    }
+}
+
 // LDS of one workgroup (two iterations of the helpers' candidates); a CU hosts 1024 / 256 = 4 workgroups of a 65 536-chain launch
 constexpr int team_lds_bytes(int d, int yd, int n, int nw) { return 2 * (n - team_main_candidates(n, nw)) * (4 + d + yd) * 64 * 4; }
 constexpr int TEAM_MAX_LDS = 40 * 1024;
@@ -398,6 +587,9 @@ constexpr bool team_config_ok(int d, int yd, int n, int nw)
 // GLABC_ERR_ARG when the configuration has no such team kernel (too few candidates, or candidates beyond the LDS budget).
 template <int D, int YD>
 int launch_team_dim(int n_batch, int nw, const StepArgs<D, YD>& a, int prio, bool fast, hipStream_t stream);
+// ... and of global_team_kernel (GlobalMCMC, Gaussian / Uniform descriptors)
+template <int D, int YD>
+int launch_global_team_dim(const StepArgs<D, YD>& a, int prio, hipStream_t stream);
 #endif
 
 }  // namespace glabc

@@ -287,6 +287,73 @@ def test_team_geometry_is_only_geometry(hip, oracle, case, waves, monkeypatch):
         assert np.array_equal(bits(hist1), bits(hist))
 
 
+GLOBAL_TEAM_CASES = [
+    # d, gf, eps, local, global, chains, T
+    (2, 0.5, 0.05, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0, 0], [1, 1]), 1000, 300),          # the bench configuration (unit variant)
+    (2, 0.3, 0.2, ("gauss", [0, 0], [0.35, 0.35]), ("gauss", [0.1, -0.1], [1.0, 1.25]), 333, 200),
+    (2, 0.7, 0.3, ("uniform", [-0.5, -0.5], [0.5, 0.5]), ("uniform", [-3, -3], [3, 3]), 130, 200),
+    (2, 0.5, 0.3, ("uniform", [-0.5, -0.5], [0.5, 0.5]), ("gauss", [0, 0], [1.2, 1.2]), 65, 200),   # normals on one branch, uniforms on the other
+    (2, 1.0, 0.3, ("gauss", [0, 0], [0.5, 0.5]), ("gauss", [0, 0], [1, 1]), 64, 100),
+    (2, 0.0, 0.3, ("gauss", [0, 0], [0.5, 0.5]), ("gauss", [0, 0], [1, 1]), 1, 100),
+    (1, 0.5, 0.3, ("gauss", [0], [0.4]), ("gauss", [0], [1]), 300, 150),
+    (3, 0.5, 0.3, ("uniform", [-0.4] * 3, [0.4] * 3), ("gauss", [0.1, 0, -0.1], [1.2, 0.9, 1]), 129, 150),
+    (4, 0.5, 0.3, ("gauss", [0] * 4, [0.3] * 4), ("uniform", [-3] * 4, [3] * 4), 300, 150),
+]
+
+
+@pytest.mark.parametrize("case", GLOBAL_TEAM_CASES, ids=lambda c: "d%d-gf%g-%s-%s" % (c[0], c[1], c[3][0], c[4][0]))
+def test_globalmcmc_team_geometry_is_only_geometry(hip, oracle, case):
+    """global_team_kernel (glabc_team.h): GlobalMCMC with two wavefronts per 64 chains -- the helper draws an iteration's random
+    numbers (branch, log u, proposal draws, simulator normals) one iteration ahead, the main wavefront does the rest -- forced
+    with GLABC_DEBUG_TEAM: histories, states, move counts and sums equal the CPU checker's and the one-wavefront kernel's, bit
+    for bit; several launches, ragged last workgroup, chain id offset; and the g-and-k Model."""
+    from glabcmcmc_amd import _capi as A
+    from glabcmcmc_amd import distribution
+    d, gf, eps, lspec, gspec, n, T = case
+    if d == 2:
+        model, local, glob = descriptors(dict(epsilon=eps, local=lspec, **{"global": gspec}))
+    else:
+        prior = distribution.DiagGaussian(d, torch.zeros(d), torch.zeros(d)).descriptor()
+        noise = distribution.DiagGaussian(d, torch.zeros(d), torch.log(torch.full((d,), 0.05).sqrt())).descriptor()
+        kern = distribution.DiagGaussian(1, torch.tensor([0.0]), torch.log(torch.tensor([eps]))).descriptor()
+        model = A.Model()
+        model.sim_kind, model.theta_dim, model.y_dim = A.SIM_ABS_GAUSS, d, d
+        model.prior, model.noise = prior, noise
+        for j in range(d):
+            model.y_obs[j] = 1.5 - 0.25 * j
+        model.kern_log_scale, model.kern_scale, model.kern_c0, model.epsilon = kern.p1[0], kern.p2[0], kern.c0, eps
+        local, glob = make_dist(lspec).descriptor(), make_dist(gspec).descriptor()
+    rng = np.random.default_rng(37 + d)
+    theta0 = rng.standard_normal((n, d)).astype(np.float32)
+    y0 = (np.abs(theta0) + 0.2236068 * rng.standard_normal((n, d))).astype(np.float32)
+    seed, chain0 = int(rng.integers(0, 2 ** 63)), int(rng.integers(0, 2 ** 40))
+    hist, chains, mom = hip_run("globalmcmc", model, local, glob, theta0, y0, T, seed, gf, 1, chain0=chain0, moments=True,
+                                steps_per_launch=41, debug_flags=A.DEBUG_TEAM)
+    hh, hc, hm = oracle_run(oracle, "globalmcmc", model, local, glob, theta0, y0, T, seed, gf, 1, chain0=chain0, moments=True)
+    same = bits(hist) == bits(hh)
+    assert same.all(), "first mismatch at (t, dim, chain) = %s" % (np.argwhere(~same)[0],)
+    assert_same_state(chains, hc, False)
+    assert np.array_equal(mom.sum_theta.cpu().numpy(), hm.sum_theta)
+    assert np.array_equal(mom.sum_jump.cpu().numpy(), hm.sum_jump)
+    assert hc.n_moves.sum() > 0
+    hist1, chains1, _ = hip_run("globalmcmc", model, local, glob, theta0, y0, T, seed, gf, 1, chain0=chain0,
+                                steps_per_launch=41, debug_flags=A.DEBUG_NO_TEAM)
+    assert np.array_equal(bits(hist1), bits(hist))
+
+
+def test_globalmcmc_team_reproduces_reference_chains_and_gk(hip, oracle):
+    """the reference's golden GlobalMCMC chains (Mixture_set and the g-and-k Model) through the team geometry"""
+    from glabcmcmc_amd import _capi as A
+    for name in [n for n in SAMPLER_GOLDENS if "philox" in n and "globalmcmc" in n]:
+        g = load_golden(name)
+        cfg = g["cfg"]
+        model, local, glob = descriptors(cfg, g)
+        hist, chains, _ = hip_run("globalmcmc", model, local, glob, g["theta0"], g["y0"], cfg["T"], cfg["seed"], cfg["gf"], 1,
+                                  chain0=cfg.get("chain0", 0), debug_flags=A.DEBUG_TEAM)
+        want = g["chains"][1:].transpose(0, 2, 1)              # (T, d, n)
+        assert (bits(hist) == bits(want)).all(), name
+
+
 @pytest.mark.parametrize("name", [n for n in SAMPLER_GOLDENS if "philox" in n and "glmcmc" in n])
 def test_team_reproduces_reference_chains(hip, name):
     """The reference's golden chains through the team geometry (where the configuration has one: batch size 2 .. 16)."""
