@@ -79,7 +79,9 @@ def load():
         # always through make: a checker older than its source must not be what the tests trust (on the GPU box the
         # prebuilt library travels with the snapshot and make finds it up to date)
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
-        h = C.CDLL(LIB_PATH)
+        # GLABC_ORACLE_LIB: another build of the same checker (e.g. one compiled with -fsanitize=address,undefined, run with
+        # LD_PRELOAD=libasan.so -- the CPU suite then walks every checker path under the sanitizers)
+        h = C.CDLL(os.environ.get("GLABC_ORACLE_LIB") or LIB_PATH)
         for name, (res, args) in _SIG.items():
             fn = getattr(h, name)
             fn.restype = res
