@@ -994,6 +994,11 @@ def test_glmala_law_matches_a_large_reference_sample(hip):
         m, r, comb = report[k]
         assert comb / abs(r) < 1e-3 and abs(m - r) / abs(r) < 2.5e-3, (k, report[k])
     tight = int(g["n_chains"]) >= 440000
+    print("GLMALA law, %d kernel chains against %d unmodified reference chains (statistic: kernel, reference, relative difference, "
+          "combined relative standard error)" % (n, int(g["n_chains"])))
+    for k in names:
+        m, r, comb = report[k]
+        print("  %-12s %.6f %.6f %+.2e %.2e" % (k, m, r, (m - r) / abs(r) if r else 0.0, comb / abs(r) if r else 0.0))
     for k in ("esjd", "move_rate"):
         m, r, comb = report[k]
         assert comb / abs(r) < (1e-3 if tight else 2e-3), (k, report[k], int(g["n_chains"]))
