@@ -932,18 +932,24 @@ def test_per_chain_global_frequency(hip, oracle, algo):
 
 
 def test_randomised_configurations_equal_oracle(hip, oracle):
-    """A few seconds of tests/fuzz_parity.py (random dimension, batch size, epsilon, frequencies, proposal kinds and
-    parameters, observations near zero, lanes, launch splits): kernels == oracle, bit for bit.  The script itself runs
-    for as long as asked (3842 configurations / 10 million accepted moves without a mismatch in round 1)."""
+    """Half a minute of tests/fuzz_parity.py in the script's own mix of cases -- random dimension, batch size (register, team
+    and wide kernels), epsilon, frequencies, proposal kinds and parameters, observations near zero, lanes, launch splits; every
+    fourth case GLMALA, every eighth the g-and-k Model, every sixteenth a random user simulator (with random user prior /
+    discrepancy / kernel) compiled at run time, now and then the flow and its gradient: kernels == checker, bit for bit (the
+    gradient within its tolerance).  The script itself runs for as long as asked (this round: 7223 + 20 655 + 621 configurations
+    without a mismatch, profiles/r03c_fuzz_*.txt, r03b_fuzz.txt)."""
     import time
-    import fuzz_parity
+    import fuzz_parity as fz
     rng = np.random.default_rng(12345)
-    t0, k = time.time(), 0
-    while time.time() - t0 < 8.0:
-        ok, desc, _ = fuzz_parity.one_case(rng, oracle, k)
+    t0, k, kinds = time.time(), 0, set()
+    while time.time() - t0 < 30.0 or k < 40:
+        fn = fz.one_case_nf_grad if k % 64 == 17 else fz.one_case_rtc if k % 16 == 6 else fz.one_case_mala if k % 4 == 3 else \
+            fz.one_case_gk if k % 8 == 5 else fz.one_case_nf if k % 32 == 9 else fz.one_case
+        ok, desc, _ = fn(rng, oracle, k)
         assert ok, desc
+        kinds.add(fn.__name__)
         k += 1
-    assert k > 20
+    assert k >= 40 and {"one_case", "one_case_mala", "one_case_gk", "one_case_rtc", "one_case_nf"} <= kinds
 
 
 @pytest.mark.gpu
