@@ -52,6 +52,17 @@ GLABC_RTC_TEAM_INST(2, VAR_GAUSS_UNIT)
 #endif
 #endif
 
+// GlobalMCMC: the team of two wavefronts (global_team_kernel: the helper draws the random numbers a chunk of iterations ahead)
+#if GLABC_RTC_ALGO == 1 && defined(GLABC_RTC_GTEAM)
+}  // namespace glabc
+#include "glabc_team.h"
+namespace glabc {
+template __global__ void global_team_kernel<GLABC_RTC_D, GLABC_RTC_YD, VAR_GENERIC, 2>(const StepArgs<GLABC_RTC_D, GLABC_RTC_YD>, int);
+#if GLABC_RTC_YD == GLABC_RTC_D && !defined(GLABC_USER_PRIOR) && !defined(GLABC_USER_DISCREPANCY) && !defined(GLABC_USER_KERNEL)
+template __global__ void global_team_kernel<GLABC_RTC_D, GLABC_RTC_YD, VAR_GAUSS_UNIT, 2>(const StepArgs<GLABC_RTC_D, GLABC_RTC_YD>, int);
+#endif
+#endif
+
 // generate_samples(theta, 1) on rows with the noise supplied (the Model protocol's callback, for y0 and the split-phase path):
 // theta[n][D], eps[n][ND] -> y[n][YD]
 extern "C" __global__ void __launch_bounds__(256) glabc_rtc_simulate_rows(const float* __restrict__ theta, const float* __restrict__ eps,

@@ -405,9 +405,14 @@ struct GlobalDraws {                        // one iteration, [field][lane]: con
                                             // Box-Muller pairs: the two wavefronts then carry about the same number of instructions)
 };
 
-template <int D, int YD, int VAR>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) global_team_kernel(const StepArgs<D, YD> a, int prio)
+// NW = 3 splits the helper's work once more: wavefront 1 draws the step head (branch, log u), wavefront 2 the candidate's Philox
+// block, the proposal's draws and the simulator's words.  Same chains; measured SLOWER than two at 65 536 chains (1.22 against
+// 1.17 ms per 2000 iterations: a third barrier party and the main wavefront's dependent chain gain nothing from it), so two is what
+// the library launches; GLABC_TEAM_WAVES=3 reaches this form (tests).
+template <int D, int YD, int VAR, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) global_team_kernel(const StepArgs<D, YD> a, int prio)
 {
+    static_assert(NW == 2 || NW == 3, "a team of two or three wavefronts");
     constexpr bool GU = (VAR == VAR_GAUSS_UNIT);
     constexpr int DP = D + (D & 1);
     constexpr int ND = NoiseDim<YD>::value;
@@ -427,35 +432,45 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) g
     rng.k1 = a.seed_hi;
     const float gf = a.gf_chain ? a.gf_chain[i] : a.gf;
 
-    if (wave != 0) {                                       // ---- helper: the draws of iteration t, one iteration ahead ----
+    if (wave != 0) {                                       // ---- helpers: the draws of a chunk of iterations, one chunk ahead ----
         const bool g_uni = !GU && a.global.kind == GLABC_DIST_UNIFORM;
         const bool l_uni = !GU && a.local.kind == GLABC_DIST_UNIFORM;
+        const bool do_head = NW == 2 || wave == 1, do_cand = NW == 2 || wave == 2;       // wave-uniform
+        const bool need_branch = do_head || g_uni != l_uni;                                // which kind of draw the proposal takes
 #pragma unroll 1
         for (int t0 = 0; t0 < a.n_steps; t0 += CH) {
 #pragma unroll 1
           for (int t = t0; t < t0 + CH && t < a.n_steps; ++t) {
             const uint32_t step = a.step0 + (uint32_t)t;
             GlobalDraws<D, YD>& o = buf[(t0 / CH) & 1][t - t0];
-            const glabc_u32x4 h = glabc_philox4x32_10(rng.c0, rng.c1, step, 0u, rng.k0, rng.k1);       // the step head, chain_step
-            const float ub = glabc_uniform_f32(h.v[0]), ua = glabc_uniform_f32(h.v[1]);
-            const bool is_global = ub < gf;                                                             // GlobalMCMC.py:39
-            o.log_u[lane] = (ua == 0.0f) ? -__builtin_inff() : glabc_logf_normal(ua);
-            o.is_global[lane] = is_global ? 1u : 0u;
-            uint32_t w[4 * SPP + 2];                       // (+2: an odd noise count reads one pad word)
-#pragma unroll
-            for (int b = 0; b < SPP; ++b) {
-                const glabc_u32x4 v = glabc_philox4x32_10(rng.c0, rng.c1, step, (uint32_t)(1 + b), rng.k0, rng.k1);   // candidate 0
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w[4 * b + q] = v.v[q];
+            bool is_global = false;
+            if (need_branch) {
+                const glabc_u32x4 h = glabc_philox4x32_10(rng.c0, rng.c1, step, 0u, rng.k0, rng.k1);   // the step head, chain_step
+                const float ub = glabc_uniform_f32(h.v[0]);
+                is_global = ub < gf;                                                                    // GlobalMCMC.py:39
+                if (do_head) {
+                    const float ua = glabc_uniform_f32(h.v[1]);
+                    o.log_u[lane] = (ua == 0.0f) ? -__builtin_inff() : glabc_logf_normal(ua);
+                    o.is_global[lane] = is_global ? 1u : 0u;
+                }
             }
-            const bool uni = is_global ? g_uni : l_uni;
-            float nrm[DP];                                 // the proposal's pairs (words 0 .. DP-1)
+            if (do_cand) {
+                uint32_t w[4 * SPP];
 #pragma unroll
-            for (int k = 0; 2 * k < DP; ++k) glabc_normal_pair(w[2 * k], w[2 * k + 1], &nrm[2 * k], &nrm[2 * k + 1]);
+                for (int b = 0; b < SPP; ++b) {
+                    const glabc_u32x4 v = glabc_philox4x32_10(rng.c0, rng.c1, step, (uint32_t)(1 + b), rng.k0, rng.k1);   // candidate 0
 #pragma unroll
-            for (int k = 0; k < D; ++k) o.e[k][lane] = (!GU && uni) ? glabc_uniform_f32(w[k]) : nrm[k];
+                    for (int q = 0; q < 4; ++q) w[4 * b + q] = v.v[q];
+                }
+                const bool uni = is_global ? g_uni : l_uni;    // (equal kinds: the branch does not matter and was not drawn)
+                float nrm[DP];                                 // the proposal's pairs (words 0 .. DP-1)
 #pragma unroll
-            for (int k = 0; k < 2 * ((ND + 1) / 2); ++k) o.sw[k][lane] = w[DP + k];
+                for (int k = 0; 2 * k < DP; ++k) glabc_normal_pair(w[2 * k], w[2 * k + 1], &nrm[2 * k], &nrm[2 * k + 1]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) o.e[k][lane] = (!GU && uni) ? glabc_uniform_f32(w[k]) : nrm[k];
+#pragma unroll
+                for (int k = 0; k < 2 * ((ND + 1) / 2); ++k) o.sw[k][lane] = w[DP + k];
+            }
           }
             __syncthreads();                               // the chunk's draws are in LDS
         }
@@ -574,6 +589,9 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) g
     }
 }
 
+// LDS of a global_team_kernel workgroup: two chunks of GLOBAL_TEAM_CHUNK iterations' draws
+constexpr int global_team_lds_bytes(int d, int nd) { return 2 * GLOBAL_TEAM_CHUNK * (2 + d + 2 * ((nd + 1) / 2)) * 64 * 4; }
+
 // LDS of one workgroup (two iterations of the helpers' candidates); a CU hosts 1024 / 256 = 4 workgroups of a 65 536-chain launch
 constexpr int team_lds_bytes(int d, int yd, int n, int nw) { return 2 * (n - team_main_candidates(n, nw)) * (4 + d + yd) * 64 * 4; }
 constexpr int TEAM_MAX_LDS = 40 * 1024;
@@ -589,7 +607,7 @@ template <int D, int YD>
 int launch_team_dim(int n_batch, int nw, const StepArgs<D, YD>& a, int prio, bool fast, hipStream_t stream);
 // ... and of global_team_kernel (GlobalMCMC, Gaussian / Uniform descriptors)
 template <int D, int YD>
-int launch_global_team_dim(const StepArgs<D, YD>& a, int prio, hipStream_t stream);
+int launch_global_team_dim(int nw, const StepArgs<D, YD>& a, int prio, hipStream_t stream);
 #endif
 
 }  // namespace glabc

@@ -64,17 +64,23 @@ int launch_team_dim<GLABC_DIM, GLABC_YDIM>(int n_batch, int nw, const StepArgs<G
     }
 }
 
-template <>
-int launch_global_team_dim<GLABC_DIM, GLABC_YDIM>(const StepArgs<GLABC_DIM, GLABC_YDIM>& a, int prio, hipStream_t s)
+template <int NW>
+static int launch_global_team(const StepArgs<GLABC_DIM, GLABC_YDIM>& a, int prio, hipStream_t s)
 {
     constexpr int D = GLABC_DIM, YD = GLABC_YDIM;
-    if (a.prior.kind == GLABC_DIST_GAMMA || a.global.kind == GLABC_DIST_GAMMA) return GLABC_ERR_ARG;      // one lane per chain
     const unsigned grid = (unsigned)((a.n_chains + 63) / 64);
     if (YD == D && gauss_unit_config<D, YD>(a))
-        hipLaunchKernelGGL((global_team_kernel<D, YD, (YD == D ? VAR_GAUSS_UNIT : VAR_GENERIC)>), dim3(grid), dim3(128), 0, s, a, prio);
+        hipLaunchKernelGGL((global_team_kernel<D, YD, (YD == D ? VAR_GAUSS_UNIT : VAR_GENERIC), NW>), dim3(grid), dim3(64 * NW), 0, s, a, prio);
     else
-        hipLaunchKernelGGL((global_team_kernel<D, YD, VAR_GENERIC>), dim3(grid), dim3(128), 0, s, a, prio);
+        hipLaunchKernelGGL((global_team_kernel<D, YD, VAR_GENERIC, NW>), dim3(grid), dim3(64 * NW), 0, s, a, prio);
     return hipGetLastError() == hipSuccess ? GLABC_OK : GLABC_ERR_LAUNCH;
+}
+
+template <>
+int launch_global_team_dim<GLABC_DIM, GLABC_YDIM>(int nw, const StepArgs<GLABC_DIM, GLABC_YDIM>& a, int prio, hipStream_t s)
+{
+    if (a.prior.kind == GLABC_DIST_GAMMA || a.global.kind == GLABC_DIST_GAMMA) return GLABC_ERR_ARG;      // one lane per chain
+    return nw == 3 ? launch_global_team<3>(a, prio, s) : launch_global_team<2>(a, prio, s);
 }
 
 }  // namespace glabc

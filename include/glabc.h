@@ -228,6 +228,9 @@ typedef struct glabc_draws_out {   /* device arrays covering exactly the call's 
  * iteration ahead).  These bits forbid / force that geometry -- tests use them to show that both give the same chains. */
 #define GLABC_DEBUG_NO_TEAM 2
 #define GLABC_DEBUG_TEAM 4
+/* (Round 3: teams of two / three wavefronts also run the Gamma variant, the g-and-k Model, GlobalMCMC -- glabc_globalmcmc_steps: a
+ * helper wavefront draws an iteration's random numbers a chunk of iterations ahead -- and the run-time compiled kernels of
+ * glabc_rtc_steps; the same two bits force / forbid the geometry there.) */
 /* One lane per chain, launches of at most two wavefronts per SIMD: the library picks the build of the kernels scheduled for
  * instruction-level parallelism; this bit picks the default-schedule build (the one larger launches get) -- so that a test
  * can walk EVERY instantiation with small launches (tests/test_slp_twin.py). */

@@ -301,12 +301,16 @@ GLOBAL_TEAM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("waves", [2, 3])
 @pytest.mark.parametrize("case", GLOBAL_TEAM_CASES, ids=lambda c: "d%d-gf%g-%s-%s" % (c[0], c[1], c[3][0], c[4][0]))
-def test_globalmcmc_team_geometry_is_only_geometry(hip, oracle, case):
+def test_globalmcmc_team_geometry_is_only_geometry(hip, oracle, case, waves, monkeypatch):
     """global_team_kernel (glabc_team.h): GlobalMCMC with two wavefronts per 64 chains -- the helper draws an iteration's random
     numbers (branch, log u, proposal draws, simulator normals) one iteration ahead, the main wavefront does the rest -- forced
     with GLABC_DEBUG_TEAM: histories, states, move counts and sums equal the CPU checker's and the one-wavefront kernel's, bit
-    for bit; several launches, ragged last workgroup, chain id offset; and the g-and-k Model."""
+    for bit; several launches, ragged last workgroup, chain id offset.  Two wavefronts (one helper), or three (one helper draws
+    the step head, the other the candidate's numbers; with a Gaussian proposal on one branch and a Uniform one on the other it
+    draws the branch as well)."""
+    monkeypatch.setenv("GLABC_TEAM_WAVES", str(waves))
     from glabcmcmc_amd import _capi as A
     from glabcmcmc_amd import distribution
     d, gf, eps, lspec, gspec, n, T = case

@@ -534,3 +534,68 @@ def test_hip_compiled_user_model_example_reaches_the_posterior(hip):
     assert torch.allclose(cm.prior_log_prob(th), ref.prior_log_prob(th).view(-1), rtol=1e-5, atol=1e-5)
     assert torch.allclose(cm.discrepancy(y), ref.discrepancy(y).view(-1), rtol=1e-5, atol=1e-6)
     assert torch.allclose(cm.calculate_log_kernel(y), ref.calculate_log_kernel(y).view(-1), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["nonlinear", "all_user", "mixture"])
+def test_hip_rtc_globalmcmc_team_is_only_geometry(hip, oracle, which):
+    """Run-time compiled GlobalMCMC kernels in the two-wavefront team geometry too (global_team_kernel: the helper draws the
+    random numbers a chunk of iterations ahead): forced either way on a small launch, and the library's own choice at 16 384
+    chains -- the same chains, bit for bit, and the checker's."""
+    import glabcmcmc_amd as g_
+    from glabcmcmc_amd import engine
+    if which == "nonlinear":
+        d, yd, nd, src = 3, 2, 4, NONLINEAR
+        prior, y_obs, eps = make_dist(("gauss", [0.0, 0.5, 0.0], [1.5, 1.0, 2.0])), [0.9, 0.6], 0.15
+    elif which == "all_user":
+        d, yd, nd, src = 2, 3, 3, ALL_USER
+        prior, y_obs, eps = make_dist(("gauss", [0.0, 0.0], [1.5, 1.5])), [1.0, 0.5, 0.7], 0.4
+    else:
+        d, yd, nd, src = 2, 2, 2, mixture_source([0.2236068, 0.2236068])
+        prior, y_obs, eps = make_dist(("gauss", [0.0, 0.0], [1.0, 1.0])), [1.5, 1.5], 0.05
+    cm = g_.CompiledModel(d, yd, src, prior, y_obs, eps, noise_dim=nd)
+    lib, fn = host_simulator(src, d, yd, nd)
+    oracle.oracle_set_user_simulator(fn)
+    oracle.oracle_set_user_model(*host_hooks(lib))
+    try:
+        model = cm.descriptor()
+        local = make_dist(("uniform", [-0.4] * d, [0.4] * d) if which == "nonlinear" else ("gauss", [0.0] * d, [0.3] * d)).descriptor()
+        glob = make_dist(("gauss", [0.0] * d, [1.0] * d if which == "mixture" else [1.5] * d)).descriptor()
+        rng = np.random.default_rng(5 + d)
+        n, T, seed, gf, chain0 = 700, 60, 4321, 0.5, 10 ** 9
+        theta0 = rng.standard_normal((n, d)).astype(np.float32)
+        y0 = cm.generate_samples(torch.from_numpy(theta0)).numpy().copy()
+        dev = torch.device("cuda", 0)
+        prog = cm.program(A.ALGO_GLOBALMCMC)
+        outs = {}
+        for name, flags in (("one-lane", A.DEBUG_NO_TEAM), ("team", A.DEBUG_TEAM)):
+            chains = engine.ChainBatch(torch.from_numpy(theta0), torch.from_numpy(y0), dev, chain0=chain0)
+            hist = torch.empty(T, d, n, device=dev)
+            mom = engine.Moments(n, d, dev)
+            engine.run_steps("glabc_globalmcmc_steps", model, local, glob, chains, T, 1, seed, gf, 1, history=hist, moments=mom,
+                             steps_per_launch=23, rtc_program=prog, debug_flags=flags)
+            torch.cuda.synchronize()
+            outs[name] = (hist.cpu().numpy(), chains.theta.cpu().numpy(), chains.y.cpu().numpy(), chains.n_moves.cpu().numpy(),
+                          mom.sum_jump.cpu().numpy(), mom.sum_outer.cpu().numpy())
+        for x, y in zip(outs["one-lane"], outs["team"]):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        hc = oracle_lib.HostChains(theta0, y0, chain0=chain0)
+        hh = np.zeros((T, d, n), np.float32)
+        run, k2 = oracle_lib.make_run(seed=seed, step0=1, n_steps=T, gf=gf, batch=1, history=hh)
+        cs = hc.struct()
+        assert oracle.oracle_globalmcmc_steps(C.byref(model), C.byref(local), C.byref(glob), C.byref(cs), C.byref(run)) == 0
+        assert np.array_equal(bits(outs["team"][0]), bits(hh)) and hc.n_moves.sum() > n // 2
+        n2, T2 = 16384, 20
+        th2 = rng.standard_normal((n2, d)).astype(np.float32)
+        y2 = cm.generate_samples(torch.from_numpy(th2)).numpy().copy()
+        res = []
+        for flags in (0, A.DEBUG_NO_TEAM):
+            chains = engine.ChainBatch(torch.from_numpy(th2), torch.from_numpy(y2), dev, chain0=5)
+            hist = torch.empty(T2, d, n2, device=dev)
+            engine.run_steps("glabc_globalmcmc_steps", model, local, glob, chains, T2, 1, seed, gf, 1, history=hist, rtc_program=prog,
+                             debug_flags=flags)
+            torch.cuda.synchronize()
+            res.append(hist.cpu().numpy())
+        assert np.array_equal(bits(res[0]), bits(res[1]))
+    finally:
+        oracle.oracle_set_user_model(None, None, None)
